@@ -1,0 +1,144 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+Generates tests/golden/*.npz by running the UNMODIFIED reference optimizer
+(/root/reference/tangram/mapping_optimizer.py, loaded standalone with importlib because
+`import tangram` needs scanpy) on CPU, in fp32 (as shipped) and in fp64 (tensors cast to double).
+Run in the authoring container only:   python oracle/gen_golden.py
+The fixtures travel to the GPU box; the reference does not.
+
+Each fixture stores the inputs' generator parameters (inputs are regenerated from the seed by
+oracle.tangram_oracle.make_synthetic), the initial logits, the per-epoch history, the final
+mapping P, the final projection P^T S, and the first-step gradient dM.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.tangram_oracle import make_synthetic, grid_graph  # noqa: E402
+
+REF = "/root/reference/tangram/mapping_optimizer.py"
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CASES = {
+    # name: (C, K, V, seed, epochs, mode, kwargs)
+    "cells_default": (300, 60, 120, 1, 60, "cells", dict(lambda_g1=1, lambda_d=1)),
+    "cells_allreg": (96, 24, 40, 2, 40, "cells",
+                     dict(lambda_g1=1, lambda_d=0.7, lambda_g2=0.5, lambda_r=1e-3, lambda_l1=1e-4, lambda_l2=1e-5)),
+    "cells_nodensity": (64, 20, 48, 3, 30, "cells", dict(lambda_g1=1, lambda_d=0, no_density=True)),
+    "clusters_dsource": (20, 80, 300, 4, 60, "clusters", dict(lambda_g1=1, lambda_d=1)),
+    "cells_ragged": (131, 37, 53, 5, 40, "cells", dict(lambda_g1=1, lambda_d=1, lambda_g2=1)),
+    "cells_spatial": (200, 40, 100, 6, 40, "spatial",
+                      dict(lambda_g1=1, lambda_d=1, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17)),
+    "constrained": (150, 40, 60, 7, 50, "constrained",
+                    dict(lambda_d=1, lambda_g1=1, lambda_g2=1, lambda_count=1, lambda_f_reg=1, target_count=40)),
+    "constrained_entropy": (90, 30, 50, 8, 30, "constrained",
+                            dict(lambda_d=1, lambda_g1=1, lambda_g2=0.3, lambda_r=1e-3, lambda_count=0.5,
+                                 lambda_f_reg=2.0, target_count=30)),
+}
+RANDOM_STATE = 42
+
+
+def load_ref():
+    spec = importlib.util.spec_from_file_location("ref_mo", REF)
+    mo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mo)
+    return mo
+
+
+def build_inputs(name):
+    C, K, V, seed, epochs, mode, kw = CASES[name]
+    kw = dict(kw)
+    data = make_synthetic(C, K, V, seed=seed, n_types=5 if mode == "spatial" else 0)
+    args = dict(S=data["S"], G=data["G"])
+    if kw.pop("no_density", False):
+        args["d"] = None
+    else:
+        args["d"] = data["d"]
+    if mode == "clusters":
+        rng = np.random.default_rng(seed + 100)
+        ds = rng.random(C).astype(np.float32)
+        args["d_source"] = ds / ds.sum()
+    if mode == "spatial":
+        args["voxel_weights"] = grid_graph(V, standardized=True, self_inclusion=True)
+        args["neighborhood_filter"] = grid_graph(V, standardized=False, self_inclusion=False)
+        args["ct_encode"] = data["ct_encode"]
+    args.update(kw)
+    return args, epochs, mode
+
+
+def to_double(mapper):
+    for k, v in list(vars(mapper).items()):
+        if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and not v.requires_grad:
+            setattr(mapper, k, v.double())
+    for nm in ("M", "F"):
+        if hasattr(mapper, nm):
+            setattr(mapper, nm, getattr(mapper, nm).detach().double().requires_grad_(True))
+    if hasattr(mapper, "getis_ord_G_star_ref"):
+        pass  # None for the cases used here
+
+
+def run(mo, name, double):
+    args, epochs, mode = build_inputs(name)
+    cls = mo.MapperConstrained if mode == "constrained" else mo.Mapper
+    mapper = cls(device="cpu", random_state=RANDOM_STATE, **args)
+    if double:
+        to_double(mapper)
+    M0 = mapper.M.detach().numpy().astype(np.float32).copy()
+    F0 = mapper.F.detach().numpy().astype(np.float32).copy() if mode == "constrained" else None
+    # first-step gradient
+    loss = mapper._loss_fn(verbose=False)[0]
+    loss.backward()
+    dM0 = mapper.M.grad.detach().numpy().copy()
+    dF0 = mapper.F.grad.detach().numpy().copy() if mode == "constrained" else None
+    mapper.M.grad = None
+    if mode == "constrained":
+        mapper.F.grad = None
+    res = mapper.train(num_epochs=epochs, learning_rate=0.1, print_each=None)
+    out = dict(M0=M0, dM0=dM0, P=res[0])
+    if mode == "constrained":
+        out.update(F0=F0, dF0=dF0, F_out=res[1])
+        hist = res[2]
+        # history entries are str(...) (mapping_optimizer.py:630); the first is "tensor(x, grad_fn=...)"
+        def parse(s):
+            s = s.replace("tensor(", "").split(",")[0].rstrip(")")
+            return float(s)
+        for k, v in hist.items():
+            out["hist_" + k] = np.array([parse(x) for x in v], dtype=np.float64)
+        f = res[1].astype(np.float64)
+        out["Ghat"] = res[0].astype(np.float64).T @ (args["S"].astype(np.float64) * f[:, None])
+    else:
+        hist = res[1]
+        for k in ["total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg"]:
+            out["hist_" + k] = np.array([float(x) for x in hist[k]], dtype=np.float64)
+        out["Ghat"] = res[0].astype(np.float64).T @ args["S"].astype(np.float64)
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    mo = load_ref()
+    for name in CASES:
+        o32 = run(mo, name, double=False)
+        o64 = run(mo, name, double=True)
+        blob = {}
+        for k, v in o32.items():
+            blob["f32_" + k] = v
+        for k, v in o64.items():
+            if k in ("M0", "F0"):
+                continue
+            blob["f64_" + k] = v
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, os.path.getsize(path) // 1024, "KiB",
+              "final main_loss f32/f64:", o32["hist_main_loss"][-1], o64["hist_main_loss"][-1])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""The oracle (closed-form NumPy restatement + torch port) against fixtures produced by the
+unmodified reference (oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tangram_oracle as orc
+from oracle.gen_golden import CASES, build_inputs
+
+NAMES = list(CASES)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _make(name, z, dtype):
+    args, epochs, mode = build_inputs(name)
+    if mode == "constrained":
+        m = orc.OracleMapperConstrained(M0=z["f32_M0"], F0=z["f32_F0"], dtype=dtype, **args)
+    else:
+        m = orc.OracleMapper(M0=z["f32_M0"], dtype=dtype, **args)
+    return m, epochs, mode
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_init_matches_reference_rng(golden_dir, name):
+    z = _load(golden_dir, name)
+    C, K, V, seed, epochs, mode, kw = CASES[name]
+    if mode == "constrained":
+        M0, F0 = orc.reference_init_MF_constrained(C, V, 42)
+        np.testing.assert_array_equal(F0, z["f32_F0"])
+    else:
+        M0 = orc.reference_init_M(C, V, 42)
+    np.testing.assert_array_equal(M0, z["f32_M0"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_first_step_gradient_fp64(golden_dir, name):
+    z = _load(golden_dir, name)
+    m, _, mode = _make(name, z, np.float64)
+    out = m.loss_and_grad()
+    dM = out[1]
+    ref = z["f64_dM0"]
+    assert np.abs(dM - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) + 1e-15
+    if mode == "constrained":
+        assert np.abs(out[2] - z["f64_dF0"]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_trajectory_fp64(golden_dir, name):
+    z = _load(golden_dir, name)
+    m, epochs, mode = _make(name, z, np.float64)
+    res = m.train(epochs, 0.1)
+    hist = res[-1]
+    for k in hist:
+        ref = z["f64_hist_" + k]
+        got = np.array(hist[k])
+        if np.isnan(ref).all():
+            assert np.isnan(got).all(), k
+        else:
+            if mode == "constrained" and k == "total_loss":
+                # the reference stores str(tensor) here (mapping_optimizer.py:630): 4 printed decimals
+                np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4, err_msg=k)
+            else:
+                np.testing.assert_allclose(got, ref, rtol=0, atol=2e-9, err_msg=k)
+    np.testing.assert_allclose(res[0], z["f64_P"], atol=1e-7)
+    if mode == "constrained":
+        np.testing.assert_allclose(res[1], z["f64_F_out"], atol=1e-7)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_trajectory_fp32_vs_reference_fp32(golden_dir, name):
+    """Same-precision comparison: tolerance = the reference's own fp32-vs-fp64 spread."""
+    z = _load(golden_dir, name)
+    m, epochs, mode = _make(name, z, np.float32)
+    res = m.train(epochs, 0.1)
+    hist = res[-1]
+    for k in ("main_loss", "total_loss", "kl_reg"):
+        ref = z["f32_hist_" + k]
+        if np.isnan(ref).all():
+            continue
+        tol = dict(rtol=1e-4, atol=1e-4) if (mode == "constrained" and k == "total_loss") else dict(rtol=0, atol=2e-5)
+        np.testing.assert_allclose(np.array(hist[k]), ref, err_msg=k, **tol)
+    assert np.abs(res[0] - z["f32_P"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("name", ["cells_default", "cells_allreg", "cells_spatial", "constrained"])
+def test_torch_port_matches_reference(golden_dir, name):
+    from oracle import torch_port as tp
+    z = _load(golden_dir, name)
+    args, epochs, mode = build_inputs(name)
+    if mode == "constrained":
+        m = tp.TorchPortMapperConstrained(M0=z["f32_M0"], F0=z["f32_F0"], **args)
+    else:
+        m = tp.TorchPortMapper(M0=z["f32_M0"], **args)
+    res = m.train(epochs, 0.1)
+    hist = res[-1]
+    for k in ("main_loss", "total_loss"):
+        tol = dict(rtol=1e-4, atol=1e-4) if (mode == "constrained" and k == "total_loss") else dict(rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.array(hist[k]), z["f32_hist_" + k], err_msg=k, **tol)
+    assert np.abs(res[0] - z["f32_P"]).max() < 1e-5
+
+
+def test_train_score_invariant():
+    """Re-creation of the reference's test_train_score_match (tests/tangram_test.py:159-210):
+    the reported main_loss equals the mean per-gene cosine recomputed from the returned mapping."""
+    data = orc.make_synthetic(120, 30, 50, seed=11)
+    m = orc.OracleMapper(data["S"], data["G"], d=data["d"], lambda_d=1, random_state=42)
+    P, hist = m.train(30)
+    m2 = orc.OracleMapper(data["S"], data["G"], d=data["d"], lambda_d=1, M0=m.M)
+    terms, _ = m2.loss_and_grad()
+    Gp = P.astype(np.float64).T @ data["S"].astype(np.float64)
+    G = data["G"].astype(np.float64)
+    cs = [(a @ b) / (np.linalg.norm(a) * np.linalg.norm(b)) for a, b in zip(G.T, Gp.T)]
+    assert round(float(np.mean(cs)), 3) == round(float(terms["main_loss"]), 3)
