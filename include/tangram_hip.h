@@ -1,0 +1,148 @@
+/*
+ * tangram_hip.h -- C ABI of the MI355X-native Tangram mapping optimizer (libtangram_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of broadinstitute/Tangram: the training loop of
+ * `tangram.mapping_optimizer.Mapper` / `MapperConstrained`
+ * (reference: tangram/mapping_optimizer.py:14-408 and :411-639), reached through
+ * `tg.map_cells_to_space()` (tangram/mapping_utils.py:141-428, operator seam at :355-363 and
+ * :383-389).  The reference has no FFI of its own (it is pure Python on top of PyTorch); each entry
+ * point below names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a
+ * Tangram maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is a device (HBM) pointer owned by the caller;
+ *   - the library allocates NO device memory: the caller provides `state` (logits + Adam moments)
+ *     and `workspace` buffers whose sizes come from tg_query_sizes();
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises
+ *     the stream except tg_mapper_read_history();
+ *   - return value 0 = success, negative = tg_status; tg_last_error() gives the message of the last
+ *     failure on the calling thread.  The library never aborts.
+ *   - a handle is not thread-safe; different handles may be used from different threads.
+ */
+#ifndef TANGRAM_HIP_H
+#define TANGRAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+typedef enum tg_status {
+    TG_OK = 0,
+    TG_ERR_INVALID = -1,     /* bad argument (maps to ValueError in the Python mirror)            */
+    TG_ERR_HIP = -2,         /* a HIP runtime call failed                                         */
+    TG_ERR_STATE = -3,       /* call sequence violated (e.g. step before setup)                   */
+    TG_ERR_UNSUPPORTED = -4  /* feature of the reference not available in this build              */
+} tg_status;
+
+typedef enum tg_mode {
+    TG_MODE_MAPPER = 0,      /* Mapper            (mapping_optimizer.py:14)  modes 'cells'/'clusters' */
+    TG_MODE_CONSTRAINED = 1  /* MapperConstrained (mapping_optimizer.py:411) mode 'constrained'       */
+} tg_mode;
+
+typedef enum tg_precision {
+    TG_PREC_F32 = 0,     /* exact fp32 matrix-core products (v_mfma_f32_16x16x4_f32)                 */
+    TG_PREC_BF16 = 1,    /* bf16 operands, fp32 accumulate                                           */
+    TG_PREC_BF16X3 = 2   /* split-bf16 (hi+lo) operands, 3 products, fp32 accumulate: fp32-parity    */
+} tg_precision;
+
+/* Hyper-parameters: Mapper.__init__ (mapping_optimizer.py:19-45) / MapperConstrained.__init__ (:417-432) */
+typedef struct tg_config {
+    int32_t abi_version;     /* TG_ABI_VERSION */
+    int32_t mode;            /* tg_mode */
+    int32_t precision;       /* tg_precision of the two GEMMs */
+    int32_t n_cells;         /* C: rows of S and M */
+    int32_t n_genes;         /* K: training genes */
+    int32_t n_spots;         /* V: spots held by THIS handle (a shard when spots are partitioned) */
+    int32_t n_spots_total;   /* V over all shards (= n_spots on one GPU) */
+    int32_t has_density;     /* d given (target_density_enabled, :114) */
+    int32_t has_d_source;    /* d_source given (:118) */
+    int32_t fwd_splits;      /* 0 = choose automatically; >0 = number of cell-range splits of the forward GEMM */
+    float lambda_g1, lambda_d, lambda_g2, lambda_r, lambda_l1, lambda_l2;
+    float lambda_count, lambda_f_reg, target_count;     /* constrained mode (:426-428, :480-483) */
+    float beta1, beta2, eps;                            /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 (:373) */
+} tg_config;
+
+typedef struct tg_sizes {
+    size_t state_bytes;      /* logits M + Adam m + Adam v (+ filter F and its moments), fp32 */
+    size_t workspace_bytes;  /* operand images of S, G copy, partial sums, coefficient vectors */
+    int32_t m_pitch;         /* row pitch of M in floats (n_spots rounded up to 64) */
+    int32_t history_terms;   /* floats per history row */
+} tg_sizes;
+
+/* Inputs of the constructor (mapping_optimizer.py:83-157): caller-owned device arrays, fp32 row-major. */
+typedef struct tg_inputs {
+    const float* S_dev;         /* [C][K]  single-cell matrix                     (:83)  */
+    const float* G_dev;         /* [V][K]  spatial matrix (this shard's rows)     (:84)  */
+    const float* d_dev;         /* [V]     density prior or NULL                  (:116) */
+    const float* d_source_dev;  /* [C]     source density or NULL                 (:120) */
+    const float* M0_dev;        /* [C][V]  initial logits, dense pitch V          (:150-157) */
+    const float* F0_dev;        /* [C]     initial filter logits (constrained)    (:490) */
+} tg_inputs;
+
+typedef struct tg_mapper tg_mapper;
+
+/* indices into a history row (floats); unused terms are NaN like the reference's filtered terms (:301) */
+enum { TG_H_TOTAL = 0, TG_H_MAIN = 1, TG_H_VG = 2, TG_H_KL = 3, TG_H_ENTROPY = 4, TG_H_L1 = 5, TG_H_L2 = 6,
+       TG_H_NB = 7, TG_H_CT = 8, TG_H_COUNT = 9, TG_H_FREG = 10, TG_H_NTERMS = 16 };
+
+/* exchange buffers of the spot-sharded multi-GPU path (device pointers inside `workspace`) */
+enum { TG_X_GENESTAT = 0,   /* [2][Kp]  per-gene (dot, |Ghat|^2) partial sums   -> all-reduce(sum) */
+       TG_X_GNORM2 = 1,     /* [Kp]     per-gene |G|^2 (set-up)                 -> all-reduce(sum) */
+       TG_X_ROWQ = 2,       /* [6][C]   per-cell row dots r_c and friends       -> all-reduce(sum) */
+       TG_X_ROWPAIR = 3     /* [2][C]   per-cell (max, sum exp) of the new row  -> all-gather      */ };
+
+int tg_abi_version(void);
+const char* tg_last_error(void);
+
+/* Sizes of the caller-provided buffers for a configuration. */
+int tg_query_sizes(const tg_config* cfg, tg_sizes* out);
+
+/* Replaces Mapper.__init__/MapperConstrained.__init__ (mapping_optimizer.py:19-157, :417-493):
+ * builds operand images of S and G, copies M0 (and F0) into `state`, zeroes the Adam moments.
+ * `S_dev`, `G_dev`, `d_dev`, `d_source_dev` are only read during this call.                       */
+int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void* state_dev, void* workspace_dev,
+                     void* hip_stream, tg_mapper** out);
+void tg_mapper_destroy(tg_mapper* m);
+
+/* Replaces the body of Mapper.train / MapperConstrained.train (mapping_optimizer.py:382-396, :621-634):
+ * runs n_steps iterations (loss, backward, Adam) with learning rate lr; writes one history row per step
+ * into history_dev[(first_row + i) * TG_H_NTERMS ...] (device memory, may be NULL).                 */
+int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row);
+
+/* Spot-sharded multi-GPU variant of one step, split at the three points where per-gene / per-cell
+ * vectors must be reduced across GPUs.  The caller performs the collectives on the
+ * exchange buffers between the phases:
+ *   phase 0 (once, after create): all-reduce TG_X_GNORM2, then tg_mapper_phase(m, 0, ...)
+ *   phase 1: forward + local gene statistics        -> all-reduce TG_X_GENESTAT
+ *   phase 2: loss, dGhat, backward row dots         -> all-reduce TG_X_ROWQ
+ *   phase 3: backward update + Adam + local softmax statistics -> all-gather TG_X_ROWPAIR into `gathered_dev`
+ *   phase 4: merge the gathered [nranks][2][C] statistics                                            */
+int tg_mapper_phase(tg_mapper* m, int phase, float lr, float* history_row_dev, const float* gathered_dev, int nranks);
+int tg_mapper_exchange_buffer(tg_mapper* m, int which, float** ptr_dev, size_t* n_floats);
+
+/* Replaces `softmax(self.M, dim=1).cpu().numpy()` (mapping_optimizer.py:407; :637-638 constrained):
+ * P_out_dev [C][V] dense, F_out_dev [C] (sigmoid(F)) or NULL.                                       */
+int tg_mapper_result(tg_mapper* m, float* P_out_dev, float* F_out_dev);
+
+/* Replaces `adata_map.X.T @ S` (mapping_utils.py:402): Ghat_out_dev [V][K] = softmax(M)^T S (times f). */
+int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev);
+
+/* Checkpoint access (the reference's adata_map resume is a stub, mapping_optimizer.py:151-153):
+ * raw pointers to M / Adam m / Adam v inside `state` and the step counter.                          */
+int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, float** m2_dev, int32_t* pitch, int64_t* step);
+int tg_mapper_set_step(tg_mapper* m, int64_t step);   /* after restoring state: recompute softmax statistics */
+
+/* Timing hooks for bench.py: HIP events recorded around each kernel of ONE step on the handle's stream.
+ * names_out receives a ';'-separated list, ms_out the per-kernel milliseconds (n_max entries).       */
+int tg_mapper_profile_step(tg_mapper* m, float lr, char* names_out, size_t names_cap, float* ms_out, int n_max,
+                           int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TANGRAM_HIP_H */

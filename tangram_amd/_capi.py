@@ -1,0 +1,113 @@
+"""ctypes binding of libtangram_hip.so (C ABI declared in include/tangram_hip.h).
+
+The product path loads the in-tree HIP library built by `__graft_entry__.build()` /
+`tangram_amd._build.build()` and fails loudly when it is missing: there is no CPU fallback.
+(The CPU test-suite installs an *emulated* build of the same sources through
+`_install_library_for_tests`; nothing else calls that hook.)
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtangram_hip.so")
+
+TG_ABI_VERSION = 1
+TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+H_NTERMS = 16
+H_TOTAL, H_MAIN, H_VG, H_KL, H_ENTROPY, H_L1, H_L2, H_NB, H_CT, H_COUNT, H_FREG = range(11)
+X_GENESTAT, X_GNORM2, X_ROWQ, X_ROWPAIR = range(4)
+
+
+class TgConfig(ct.Structure):
+    _fields_ = [(n, ct.c_int32) for n in
+                ("abi_version", "mode", "precision", "n_cells", "n_genes", "n_spots", "n_spots_total",
+                 "has_density", "has_d_source", "fwd_splits")] + \
+               [(n, ct.c_float) for n in
+                ("lambda_g1", "lambda_d", "lambda_g2", "lambda_r", "lambda_l1", "lambda_l2",
+                 "lambda_count", "lambda_f_reg", "target_count", "beta1", "beta2", "eps")]
+
+
+class TgSizes(ct.Structure):
+    _fields_ = [("state_bytes", ct.c_size_t), ("workspace_bytes", ct.c_size_t),
+                ("m_pitch", ct.c_int32), ("history_terms", ct.c_int32)]
+
+
+class TgInputs(ct.Structure):
+    _fields_ = [(n, ct.c_void_p) for n in ("S_dev", "G_dev", "d_dev", "d_source_dev", "M0_dev", "F0_dev")]
+
+
+_lib = None
+_is_sim = False
+
+
+def _declare(lib):
+    vp, i32, f32 = ct.c_void_p, ct.c_int, ct.c_float
+    lib.tg_abi_version.restype = i32
+    lib.tg_last_error.restype = ct.c_char_p
+    lib.tg_query_sizes.argtypes = [ct.POINTER(TgConfig), ct.POINTER(TgSizes)]
+    lib.tg_mapper_create.argtypes = [ct.POINTER(TgConfig), ct.POINTER(TgInputs), vp, vp, vp, ct.POINTER(vp)]
+    lib.tg_mapper_destroy.argtypes = [vp]
+    lib.tg_mapper_destroy.restype = None
+    lib.tg_mapper_step.argtypes = [vp, i32, f32, vp, i32]
+    lib.tg_mapper_phase.argtypes = [vp, i32, f32, vp, vp, i32]
+    lib.tg_mapper_exchange_buffer.argtypes = [vp, i32, ct.POINTER(vp), ct.POINTER(ct.c_size_t)]
+    lib.tg_mapper_result.argtypes = [vp, vp, vp]
+    lib.tg_mapper_project.argtypes = [vp, vp]
+    lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
+                                    ct.POINTER(ct.c_int64)]
+    lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
+    lib.tg_mapper_profile_step.argtypes = [vp, f32, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_float), i32,
+                                           ct.POINTER(i32)]
+    for name in ("tg_query_sizes", "tg_mapper_create", "tg_mapper_step", "tg_mapper_phase",
+                 "tg_mapper_exchange_buffer", "tg_mapper_result", "tg_mapper_project", "tg_mapper_state",
+                 "tg_mapper_set_step", "tg_mapper_profile_step"):
+        getattr(lib, name).restype = i32
+    return lib
+
+
+EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
+           "tg_mapper_step", "tg_mapper_phase", "tg_mapper_exchange_buffer", "tg_mapper_result",
+           "tg_mapper_project", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile_step"]
+
+
+def lib():
+    """The loaded HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). tangram_amd has no CPU fallback.")
+        _lib = _declare(ct.CDLL(LIB_PATH))
+        if _lib.tg_abi_version() != TG_ABI_VERSION:
+            raise RuntimeError("libtangram_hip.so ABI version mismatch")
+    return _lib
+
+
+def is_emulated():
+    return _is_sim
+
+
+def _install_library_for_tests(path):
+    """TEST HOOK: use an emulated (TG_SIM) build of the same C ABI; `None` restores the HIP library."""
+    global _lib, _is_sim
+    if path is None:
+        _lib, _is_sim = None, False
+    else:
+        _lib, _is_sim = _declare(ct.CDLL(path)), True
+
+
+class TangramHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().tg_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise TangramHipError(f"libtangram_hip error {rc}: {msg}")

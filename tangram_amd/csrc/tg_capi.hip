@@ -1,0 +1,566 @@
+// tg_capi.hip -- host side of libtangram_hip.so: the C ABI of include/tangram_hip.h.
+// Enqueues the kernels of tg_kernels.h on the caller's stream; allocates nothing on the device.
+#include "../../include/tangram_hip.h"
+#include "tg_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#ifdef TG_SIM
+typedef void* tg_stream_t;
+#define TG_LAUNCH(kern, gx, gy, block, lds, stream, ...) \
+    hipsim::launch(hipsim::uint3s{(unsigned)(gx), (unsigned)(gy), 1u}, hipsim::uint3s{(unsigned)(block), 1u, 1u}, [&] { kern(__VA_ARGS__); })
+static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, tg_stream_t) {
+    for (size_t r = 0; r < height; ++r) memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
+    return 0;
+}
+static int tg_memset(void* dst, int v, size_t n, tg_stream_t) { memset(dst, v, n); return 0; }
+static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t) { memcpy(dst, src, n); return 0; }
+static int tg_check_launch() { return 0; }
+#else
+typedef hipStream_t tg_stream_t;
+#define TG_LAUNCH(kern, gx, gy, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy), 1), dim3((unsigned)(block), 1, 1), (size_t)(lds), stream, __VA_ARGS__)
+static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, tg_stream_t s) {
+    return (int)hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, s);
+}
+static int tg_memset(void* dst, int v, size_t n, tg_stream_t s) { return (int)hipMemsetAsync(dst, v, n, s); }
+static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t s) {
+    return (int)hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
+}
+static int tg_check_launch() { return (int)hipGetLastError(); }
+#endif
+
+// ----------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int tg_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+extern "C" const char* tg_last_error(void) { return g_err.c_str(); }
+extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+struct TgLayout {
+    int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, NS, ESZ, BKE, prec, full;
+    size_t o_Sk[2], o_St[2], o_dG[2], o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
+        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, total;
+    size_t s_M, s_m1, s_m2, s_F, s_total;
+};
+
+static int tg_choose_splits(int tiles, int nsteps, int slots) {
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 8 && s <= nsteps; ++s) {
+        const long w = (long)tiles * s;
+        const long waves = (w + slots - 1) / slots;
+        const double eff = (double)w / (double)(waves * slots);
+        if (eff > best_eff + 0.03) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
+static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
+    if (!cfg) return tg_fail(TG_ERR_INVALID, "null config");
+    if (cfg->abi_version != TG_ABI_VERSION) return tg_fail(TG_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, TG_ABI_VERSION);
+    if (cfg->n_cells < 1 || cfg->n_genes < 1 || cfg->n_spots < 1) return tg_fail(TG_ERR_INVALID, "empty problem: C=%d K=%d V=%d", cfg->n_cells, cfg->n_genes, cfg->n_spots);
+    if (cfg->precision < 0 || cfg->precision > 2) return tg_fail(TG_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->mode != TG_MODE_MAPPER && cfg->mode != TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_INVALID, "unknown mode %d", cfg->mode);
+    if (cfg->lambda_g1 == 0.f) return tg_fail(TG_ERR_INVALID, "lambda_g1 cannot be 0.");   // mapping_utils.py:206-207
+    if (cfg->has_d_source && !cfg->has_density) return tg_fail(TG_ERR_INVALID, "d_source requires d");
+    memset(L, 0, sizeof *L);
+    L->C = cfg->n_cells; L->K = cfg->n_genes; L->V = cfg->n_spots;
+    L->Vtot = cfg->n_spots_total > 0 ? cfg->n_spots_total : cfg->n_spots;
+    L->prec = cfg->precision;
+    L->NS = cfg->precision == TG_PREC_BF16X3 ? 2 : 1;
+    L->ESZ = cfg->precision == TG_PREC_F32 ? 4 : 2;
+    L->BKE = cfg->precision == TG_PREC_F32 ? 32 : 64;
+    L->Kp = (int)rup((size_t)L->K + 1, 128);
+    L->Vp = (int)rup(L->V, 64);
+    L->Vr = (int)rup(L->V, 128);
+    L->Cp = (int)rup(L->C, 64);
+    L->Cr = (int)rup(L->C, 128);
+    L->nvt = L->Vr / 128; L->nct = L->Cr / 128; L->nkt = L->Kp / 128;
+    L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
+    L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
+    const int nsteps = L->Cp / L->BKE;
+    const int slots = 256 * (L->NS == 2 ? 1 : 2);
+    L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots);
+    if (L->nsplit > nsteps) L->nsplit = nsteps;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
+    for (int p = 0; p < 2; ++p) {
+        L->o_Sk[p] = take((size_t)L->Cr * L->Kp * L->ESZ);
+        L->o_St[p] = take((size_t)L->Kp * L->Cp * L->ESZ);
+        L->o_dG[p] = take((size_t)L->Vr * L->Kp * L->ESZ);
+        if (L->NS == 1) { break; }
+    }
+    if (L->NS == 1) { L->o_Sk[1] = L->o_Sk[0]; L->o_St[1] = L->o_St[0]; L->o_dG[1] = L->o_dG[0]; }
+    L->o_Gp = take((size_t)L->Vr * L->Kp * 4);
+    L->o_Ghat = take((size_t)L->Vr * L->Kp * 4);
+    L->o_Gpart = take((size_t)L->nsplit * L->Vr * L->Kp * 4);
+    L->o_genepart = take((size_t)L->nrb * 2 * L->Kp * 4);
+    L->o_genestat = take((size_t)2 * L->Kp * 4);
+    L->o_gnorm2 = take((size_t)L->Kp * 4);
+    L->o_voxstat = take((size_t)2 * L->Vr * 4);
+    L->o_vnorm2 = take((size_t)L->Vr * 4);
+    L->o_d = take((size_t)L->Vr * 4);
+    L->o_coef = take((size_t)2 * L->Kp * 4);
+    L->o_vcoef = take((size_t)3 * L->Vr * 4);
+    L->o_rshift = take((size_t)L->Cp * 4);
+    L->o_rinvz = take((size_t)L->Cp * 4);
+    L->o_rscale = take((size_t)L->Cp * 4);
+    L->o_fgate = take((size_t)L->Cp * 4);
+    L->o_densw = take((size_t)L->Cp * 4);
+    const size_t np1 = L->full ? TGP1_N : 1;
+    L->o_part = take((size_t)L->nvt * (np1 > 2 ? np1 : 2) * L->C * 4);
+    L->o_rowq = take((size_t)TGP1_N * L->C * 4);
+    L->o_rowpair = take((size_t)2 * L->C * 4);
+    L->o_scal = take(64 * 4);
+    L->total = off;
+    size_t so = 0;
+    auto stake = [&](size_t bytes) { size_t o = so; so += rup(bytes, 256); return o; };
+    L->s_M = stake((size_t)L->C * L->Vp * 4);
+    L->s_m1 = stake((size_t)L->C * L->Vp * 4);
+    L->s_m2 = stake((size_t)L->C * L->Vp * 4);
+    L->s_F = stake((size_t)3 * L->Cp * 4);
+    L->s_total = so;
+    return TG_OK;
+}
+
+extern "C" int tg_query_sizes(const tg_config* cfg, tg_sizes* out) {
+    TgLayout L;
+    int rc = tg_make_layout(cfg, &L);
+    if (rc) return rc;
+    if (!out) return tg_fail(TG_ERR_INVALID, "null out");
+    out->state_bytes = L.s_total;
+    out->workspace_bytes = L.total;
+    out->m_pitch = L.Vp;
+    out->history_terms = TG_H_NTERMS;
+    return TG_OK;
+}
+
+struct tg_mapper {
+    tg_config cfg;
+    TgLayout L;
+    unsigned char* ws;
+    unsigned char* st;
+    tg_stream_t stream;
+    int64_t step;
+    bool ready;
+    // profiling
+    bool prof;
+    std::vector<std::string> prof_names;
+#ifndef TG_SIM
+    std::vector<hipEvent_t> prof_events;
+#endif
+    float* fp(size_t off) const { return (float*)(ws + off); }
+};
+
+#define TG_CK(expr)                                                                          \
+    do {                                                                                     \
+        int _e = (int)(expr);                                                                \
+        if (_e != 0) return tg_fail(TG_ERR_HIP, "%s failed with HIP error %d (%s:%d)", #expr, _e, __FILE__, __LINE__); \
+    } while (0)
+
+static void tg_prof_mark(tg_mapper* m, const char* name) {
+    if (!m->prof) return;
+#ifndef TG_SIM
+    hipEvent_t e;
+    hipEventCreate(&e);
+    hipEventRecord(e, m->stream);
+    m->prof_events.push_back(e);
+#endif
+    m->prof_names.push_back(name);
+}
+
+template <class PR>
+static int tg_lds_attr() {
+#ifndef TG_SIM
+    const int bytes = 2 * TgStage<PR>::kBytes;
+    TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+#endif
+    return TG_OK;
+}
+
+// ---- set-up ------------------------------------------------------------------------------------
+template <class PR>
+static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
+    const TgLayout& L = m->L;
+    TgPrepSArgs a;
+    a.S = in->S_dev; a.C = L.C; a.K = L.K;
+    a.aug = m->cfg.has_d_source ? in->d_source_dev : nullptr;
+    a.Sk[0] = m->ws + L.o_Sk[0]; a.Sk[1] = m->ws + L.o_Sk[1]; a.Cr = L.Cr; a.Kp = L.Kp;
+    a.St[0] = m->ws + L.o_St[0]; a.St[1] = m->ws + L.o_St[1]; a.Cp = L.Cp;
+    const size_t n1 = (size_t)L.Cr * (L.Kp / PR::CH), n2 = (size_t)L.Kp * (L.Cp / PR::CH);
+    TG_LAUNCH((tg_prep_sk<PR>), (n1 + 255) / 256, 1, 256, 0, m->stream, a);
+    TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
+    TG_CK(tg_check_launch());
+    return tg_lds_attr<PR>();
+}
+
+static int tg_softmax_stats_from_scratch(tg_mapper* m) {
+    const TgLayout& L = m->L;
+    float* M = (float*)(m->st + L.s_M);
+    TG_LAUNCH(tg_row_stats, L.C, 1, 256, 64, m->stream, (const float*)M, L.C, L.V, L.Vp, m->fp(L.o_rowpair));
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize, bool want_pair) {
+    const TgLayout& L = m->L;
+    TgMergeArgs a;
+    a.part = parts; a.nparts = nparts; a.C = L.C;
+    a.rshift = finalize ? m->fp(L.o_rshift) : nullptr;
+    a.rinvz = m->fp(L.o_rinvz);
+    a.rscale = m->fp(L.o_rscale);
+    a.pair_out = want_pair ? m->fp(L.o_rowpair) : nullptr;
+    a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
+    TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void* state_dev, void* workspace_dev,
+                                void* hip_stream, tg_mapper** out) {
+    TgLayout L;
+    int rc = tg_make_layout(cfg, &L);
+    if (rc) return rc;
+    if (!in || !state_dev || !workspace_dev || !out) return tg_fail(TG_ERR_INVALID, "null argument");
+    if (!in->S_dev || !in->G_dev || !in->M0_dev) return tg_fail(TG_ERR_INVALID, "S, G and M0 are required");
+    if (cfg->has_density && !in->d_dev) return tg_fail(TG_ERR_INVALID, "has_density set but d is NULL");
+    if (cfg->has_d_source && !in->d_source_dev) return tg_fail(TG_ERR_INVALID, "has_d_source set but d_source is NULL");
+    if (cfg->mode == TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_UNSUPPORTED, "constrained mode is not built yet");
+    tg_mapper* m = new (std::nothrow) tg_mapper();
+    if (!m) return tg_fail(TG_ERR_INVALID, "out of host memory");
+    m->cfg = *cfg; m->L = L;
+    m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
+    m->stream = (tg_stream_t)hip_stream;
+    m->step = 0; m->ready = false; m->prof = false;
+    auto bail = [&](int code) { delete m; return code; };
+
+    if (tg_memset(m->ws, 0, L.total, m->stream)) return bail(tg_fail(TG_ERR_HIP, "memset(workspace) failed"));
+    if (tg_memset(m->st, 0, L.s_total, m->stream)) return bail(tg_fail(TG_ERR_HIP, "memset(state) failed"));
+    // M0 [C][V] dense -> M [C][Vp]   (mapping_optimizer.py:155-157)
+    if (tg_memcpy2d(m->st + L.s_M, (size_t)L.Vp * 4, in->M0_dev, (size_t)L.V * 4, (size_t)L.V * 4, L.C, m->stream))
+        return bail(tg_fail(TG_ERR_HIP, "copy of M0 failed"));
+    if (cfg->has_density && tg_memcpy(m->ws + L.o_d, in->d_dev, (size_t)L.V * 4, m->stream))
+        return bail(tg_fail(TG_ERR_HIP, "copy of d failed"));
+    if (cfg->has_d_source && tg_memcpy(m->ws + L.o_densw, in->d_source_dev, (size_t)L.C * 4, m->stream))
+        return bail(tg_fail(TG_ERR_HIP, "copy of d_source failed"));
+
+    switch (cfg->precision) {
+        case TG_PREC_F32: rc = tg_setup_operands<PrecF32>(m, in); break;
+        case TG_PREC_BF16: rc = tg_setup_operands<PrecBF16>(m, in); break;
+        default: rc = tg_setup_operands<PrecBF16x3>(m, in); break;
+    }
+    if (rc) return bail(rc);
+    // padded G, |G_v|^2, |G_k|^2 partials (reuse genepart as scratch)
+    TG_LAUNCH(tg_prep_g, L.nrb, 1, 256, 4 * TG_RB * 4, m->stream, in->G_dev, L.V, L.K, L.Vr, L.Kp, m->fp(L.o_Gp),
+              m->fp(L.o_vnorm2), m->fp(L.o_genepart));
+    TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_genepart), L.nrb, L.Kp,
+              m->fp(L.o_gnorm2));
+    // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
+    TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
+    if (tg_check_launch()) return bail(tg_fail(TG_ERR_HIP, "set-up kernel launch failed"));
+    rc = tg_softmax_stats_from_scratch(m);
+    if (!rc) rc = tg_merge(m, m->fp(L.o_rowpair), 1, /*finalize=*/true, /*want_pair=*/false);
+    if (rc) return bail(rc);
+    m->ready = true;
+    *out = m;
+    return TG_OK;
+}
+
+extern "C" void tg_mapper_destroy(tg_mapper* m) { delete m; }
+
+// ---- one iteration ------------------------------------------------------------------------------
+template <class PR>
+static int tg_launch_forward(tg_mapper* m) {
+    const TgLayout& L = m->L;
+    TgFwdArgs a;
+    a.M = (const float*)(m->st + L.s_M);
+    a.rshift = m->fp(L.o_rshift); a.rscale = m->fp(L.o_rscale);
+    a.St[0] = m->ws + L.o_St[0]; a.St[1] = m->ws + L.o_St[1];
+    a.Gpart = m->fp(L.o_Gpart);
+    a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
+    a.nkt = L.nkt; a.nsteps = L.Cp / PR::BKE;
+    TG_LAUNCH((tg_fwd_kernel<PR>), L.nvt * L.nkt, L.nsplit, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    tg_prof_mark(m, "tg_fwd_kernel");
+    return TG_OK;
+}
+
+static int tg_launch_ghat_stats(tg_mapper* m) {
+    const TgLayout& L = m->L;
+    TgGhatReduceArgs a;
+    a.Gpart = m->fp(L.o_Gpart); a.nsplit = L.nsplit; a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
+    a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat);
+    a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = (m->cfg.lambda_g2 != 0.f);
+    const int nrb = (L.V + TG_RB - 1) / TG_RB;
+    TG_LAUNCH(tg_ghat_reduce, nrb, 1, 256, 4 * TG_RB * 2 * 4, m->stream, a);
+    tg_prof_mark(m, "tg_ghat_reduce");
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
+              m->fp(L.o_genestat));
+    tg_prof_mark(m, "tg_gene_reduce");
+    return TG_OK;
+}
+
+template <class PR>
+static int tg_launch_loss(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgFinalizeArgs f;
+    f.genestat = m->fp(L.o_genestat); f.gnorm2 = m->fp(L.o_gnorm2); f.Ghat = m->fp(L.o_Ghat);
+    f.voxstat = m->fp(L.o_voxstat); f.vnorm2 = m->fp(L.o_vnorm2); f.d = m->fp(L.o_d);
+    f.coef = m->fp(L.o_coef); f.vcoef = m->fp(L.o_vcoef);
+    f.hist = hist_row ? hist_row : m->fp(L.o_scal);
+    f.lambda_g1 = m->cfg.lambda_g1; f.lambda_g2 = m->cfg.lambda_g2; f.lambda_d = m->cfg.lambda_d;
+    f.rho_scale = m->cfg.has_d_source ? 1.f : 1.f / (float)L.C;
+    f.K = L.K; f.Kp = L.Kp; f.V = L.V; f.Vr = L.Vr; f.V_total = L.Vtot; f.has_density = m->cfg.has_density;
+    TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 64, m->stream, f);
+    tg_prof_mark(m, "tg_loss_finalize");
+    TgEmitArgs e;
+    e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
+    e.dG[0] = m->ws + L.o_dG[0]; e.dG[1] = m->ws + L.o_dG[1];
+    e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K;
+    TG_LAUNCH((tg_dghat_emit<PR>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
+    tg_prof_mark(m, "tg_dghat_emit");
+    return TG_OK;
+}
+
+template <class PR>
+static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
+    const TgLayout& L = m->L;
+    a.dG[0] = m->ws + L.o_dG[0]; a.dG[1] = m->ws + L.o_dG[1];
+    a.Sk[0] = m->ws + L.o_Sk[0]; a.Sk[1] = m->ws + L.o_Sk[1];
+    a.M = (float*)(m->st + L.s_M); a.am = (float*)(m->st + L.s_m1); a.av = (float*)(m->st + L.s_m2);
+    a.rshift = m->fp(L.o_rshift); a.rinvz = m->fp(L.o_rinvz);
+    a.fgate = nullptr;
+    a.vcoef = m->fp(L.o_vcoef);
+    a.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
+    a.r = m->fp(L.o_rowq);
+    a.part = m->fp(L.o_part);
+    a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nct = L.nct;
+    a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
+    a.step_size = 0.f; a.bc2_sqrt = 1.f; a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
+}
+
+template <class PR>
+static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgBwdArgs a;
+    tg_fill_bwd<PR>(m, a);
+    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 1, true>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    else TG_LAUNCH((tg_bwd_kernel<PR, 1, false>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    tg_prof_mark(m, "tg_bwd_kernel<rowdot>");
+    TgRowsumArgs r;
+    r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
+    TG_LAUNCH(tg_rowsum_parts, (L.C + 255) / 256, 1, 256, 0, m->stream, r);
+    tg_prof_mark(m, "tg_rowsum_parts");
+    if (L.full) {
+        TgHistRegArgs h;
+        h.rowq = m->fp(L.o_rowq); h.C = L.C; h.hist = hist_row ? hist_row : m->fp(L.o_scal);
+        h.lambda_r = m->cfg.lambda_r; h.lambda_l1 = m->cfg.lambda_l1; h.lambda_l2 = m->cfg.lambda_l2;
+        TG_LAUNCH(tg_hist_regs, 1, 1, 1024, 64, m->stream, h);
+        tg_prof_mark(m, "tg_hist_regs");
+    }
+    return TG_OK;
+}
+
+template <class PR>
+static int tg_launch_update(tg_mapper* m, float lr) {
+    const TgLayout& L = m->L;
+    TgBwdArgs a;
+    tg_fill_bwd<PR>(m, a);
+    const double t = (double)(m->step + 1);
+    const double bc1 = 1.0 - pow((double)m->cfg.beta1, t);
+    const double bc2 = 1.0 - pow((double)m->cfg.beta2, t);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 2, true>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    else TG_LAUNCH((tg_bwd_kernel<PR, 2, false>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    tg_prof_mark(m, "tg_bwd_kernel<update>");
+    return TG_OK;
+}
+
+template <class PR>
+static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
+    int rc;
+    if ((rc = tg_launch_forward<PR>(m))) return rc;
+    if ((rc = tg_launch_ghat_stats(m))) return rc;
+    if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
+    if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
+    if ((rc = tg_launch_update<PR>(m, lr))) return rc;
+    if ((rc = tg_merge(m, m->fp(m->L.o_part), m->L.nvt, true, false))) return rc;
+    tg_prof_mark(m, "tg_merge_stats");
+    m->step += 1;
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row) {
+    switch (m->cfg.precision) {
+        case TG_PREC_F32: return tg_one_step<PrecF32>(m, lr, hist_row);
+        case TG_PREC_BF16: return tg_one_step<PrecBF16>(m, lr, hist_row);
+        default: return tg_one_step<PrecBF16x3>(m, lr, hist_row);
+    }
+}
+
+extern "C" int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    if (n_steps < 0) return tg_fail(TG_ERR_INVALID, "n_steps < 0");
+    for (int i = 0; i < n_steps; ++i) {
+        float* row = history_dev ? history_dev + (size_t)(first_row + i) * TG_H_NTERMS : nullptr;
+        int rc = tg_dispatch_step(m, lr, row);
+        if (rc) return rc;
+    }
+    return TG_OK;
+}
+
+template <class PR>
+static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, const float* gathered, int nranks) {
+    const TgLayout& L = m->L;
+    int rc = TG_OK;
+    switch (phase) {
+        case 0: break;   // gnorm2 has been all-reduced in place by the caller; nothing else to do
+        case 1:
+            if ((rc = tg_launch_forward<PR>(m))) return rc;
+            rc = tg_launch_ghat_stats(m);
+            break;
+        case 2:
+            if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
+            rc = tg_launch_rowdots<PR>(m, hist_row);
+            break;
+        case 3:
+            if ((rc = tg_launch_update<PR>(m, lr))) return rc;
+            rc = tg_merge(m, m->fp(L.o_part), L.nvt, false, true);
+            m->step += 1;
+            break;
+        case 4:
+            if (!gathered || nranks < 1) return tg_fail(TG_ERR_INVALID, "phase 4 needs the gathered statistics");
+            rc = tg_merge(m, gathered, nranks, true, false);
+            break;
+        default: return tg_fail(TG_ERR_INVALID, "unknown phase %d", phase);
+    }
+    if (rc) return rc;
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+extern "C" int tg_mapper_phase(tg_mapper* m, int phase, float lr, float* history_row_dev, const float* gathered_dev, int nranks) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    switch (m->cfg.precision) {
+        case TG_PREC_F32: return tg_phase_impl<PrecF32>(m, phase, lr, history_row_dev, gathered_dev, nranks);
+        case TG_PREC_BF16: return tg_phase_impl<PrecBF16>(m, phase, lr, history_row_dev, gathered_dev, nranks);
+        default: return tg_phase_impl<PrecBF16x3>(m, phase, lr, history_row_dev, gathered_dev, nranks);
+    }
+}
+
+extern "C" int tg_mapper_exchange_buffer(tg_mapper* m, int which, float** ptr_dev, size_t* n_floats) {
+    if (!m || !ptr_dev || !n_floats) return tg_fail(TG_ERR_INVALID, "null argument");
+    const TgLayout& L = m->L;
+    switch (which) {
+        case TG_X_GENESTAT: *ptr_dev = m->fp(L.o_genestat); *n_floats = (size_t)2 * L.Kp; break;
+        case TG_X_GNORM2: *ptr_dev = m->fp(L.o_gnorm2); *n_floats = (size_t)L.Kp; break;
+        case TG_X_ROWQ: *ptr_dev = m->fp(L.o_rowq); *n_floats = (size_t)(L.full ? TGP1_N : 1) * L.C; break;
+        case TG_X_ROWPAIR: *ptr_dev = m->fp(L.o_rowpair); *n_floats = (size_t)2 * L.C; break;
+        default: return tg_fail(TG_ERR_INVALID, "unknown exchange buffer %d", which);
+    }
+    return TG_OK;
+}
+
+// ---- results ------------------------------------------------------------------------------------
+extern "C" int tg_mapper_result(tg_mapper* m, float* P_out_dev, float* F_out_dev) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    if (!P_out_dev) return tg_fail(TG_ERR_INVALID, "P_out is NULL");
+    (void)F_out_dev;
+    const TgLayout& L = m->L;
+    TG_LAUNCH(tg_softmax_out, L.C, 1, 256, 0, m->stream, (const float*)(m->st + L.s_M),
+              (const float*)m->fp(L.o_rshift), (const float*)m->fp(L.o_rinvz), L.C, L.V, L.Vp, P_out_dev);
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+extern "C" int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    if (!Ghat_out_dev) return tg_fail(TG_ERR_INVALID, "Ghat_out is NULL");
+    const TgLayout& L = m->L;
+    int rc;
+    switch (m->cfg.precision) {
+        case TG_PREC_F32: rc = tg_launch_forward<PrecF32>(m); break;
+        case TG_PREC_BF16: rc = tg_launch_forward<PrecBF16>(m); break;
+        default: rc = tg_launch_forward<PrecBF16x3>(m); break;
+    }
+    if (rc) return rc;
+    if ((rc = tg_launch_ghat_stats(m))) return rc;
+    TG_CK(tg_memcpy2d(Ghat_out_dev, (size_t)L.K * 4, m->ws + L.o_Ghat, (size_t)L.Kp * 4, (size_t)L.K * 4, L.V, m->stream));
+    return TG_OK;
+}
+
+extern "C" int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, float** m2_dev, int32_t* pitch, int64_t* step) {
+    if (!m) return tg_fail(TG_ERR_INVALID, "null mapper");
+    if (M_dev) *M_dev = (float*)(m->st + m->L.s_M);
+    if (m1_dev) *m1_dev = (float*)(m->st + m->L.s_m1);
+    if (m2_dev) *m2_dev = (float*)(m->st + m->L.s_m2);
+    if (pitch) *pitch = m->L.Vp;
+    if (step) *step = m->step;
+    return TG_OK;
+}
+
+extern "C" int tg_mapper_set_step(tg_mapper* m, int64_t step) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    if (step < 0) return tg_fail(TG_ERR_INVALID, "step < 0");
+    m->step = step;
+    int rc = tg_softmax_stats_from_scratch(m);
+    if (!rc) rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false);
+    return rc;
+}
+
+extern "C" int tg_mapper_profile_step(tg_mapper* m, float lr, char* names_out, size_t names_cap, float* ms_out, int n_max,
+                                      int* n_out) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    m->prof = true;
+    m->prof_names.clear();
+#ifndef TG_SIM
+    m->prof_events.clear();
+#endif
+    tg_prof_mark(m, "start");
+    int rc = tg_dispatch_step(m, lr, nullptr);
+    m->prof = false;
+    if (rc) return rc;
+    int n = (int)m->prof_names.size() - 1;
+    std::string names;
+#ifndef TG_SIM
+    TG_CK(hipStreamSynchronize(m->stream));
+#endif
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+#ifndef TG_SIM
+        hipEventElapsedTime(&ms, m->prof_events[i], m->prof_events[i + 1]);
+#endif
+        if (i < n_max && ms_out) ms_out[i] = ms;
+        if (i) names += ";";
+        names += m->prof_names[i + 1];
+    }
+#ifndef TG_SIM
+    for (auto e : m->prof_events) hipEventDestroy(e);
+    m->prof_events.clear();
+#endif
+    if (names_out && names_cap) { strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
+    if (n_out) *n_out = n;
+    return TG_OK;
+}

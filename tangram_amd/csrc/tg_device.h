@@ -1,0 +1,142 @@
+// tg_device.h -- device-side vocabulary of the Tangram MI355X kernels (gfx950 / CDNA4 only).
+//
+// Two build modes:
+//   (default) hipcc --offload-arch=gfx950: the real thing, MFMA builtins, 64-wide wavefronts.
+//   -DTG_SIM  host clang + tests/hipsim/hipsim.h: test-only emulation used by the CPU test-suite
+//             (the authoring container has no GPU).  Nothing in the product loads a TG_SIM build.
+#pragma once
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef TG_SIM
+// ------------------------------------------------------------------------------------------
+#include "hipsim.h"
+#define TG_KERNEL
+#define TG_DEV static inline
+#define TG_DEVM inline
+#define TG_LAUNCH_BOUNDS(n)
+#define threadIdx (hipsim::M().cur->tid)
+#define blockIdx (hipsim::M().blockIdx)
+#define blockDim (hipsim::M().blockDim)
+#define gridDim (hipsim::M().gridDim)
+#define TG_LDS_DECL unsigned char* tg_lds = hipsim::M().lds
+#define __syncthreads() hipsim::block_barrier()
+TG_DEV float tg_exp(float x) { return expf(x); }
+TG_DEV float tg_log(float x) { return logf(x); }
+TG_DEV float tg_rcp(float x) { return 1.0f / x; }
+TG_DEV float tg_shfl_xor(float v, int mask) { return hipsim::shfl_idx(v, hipsim::lane_id() ^ mask); }
+TG_DEV int tg_lane() { return hipsim::lane_id(); }
+TG_DEV int tg_uniform(int x) { return x; }
+TG_DEV unsigned tg_pack_bf16(float lo, float hi) {
+    return unsigned(hipsim::f32_to_bf16(lo)) | (unsigned(hipsim::f32_to_bf16(hi)) << 16);
+}
+TG_DEV f32x4 tg_mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    float t[4] = {c[0], c[1], c[2], c[3]};
+    hipsim::mfma16_bf16(&a, &b, t);
+    return f32x4{t[0], t[1], t[2], t[3]};
+}
+TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) {
+    float t[4] = {c[0], c[1], c[2], c[3]};
+    hipsim::mfma16_f32(a, b, t);
+    return f32x4{t[0], t[1], t[2], t[3]};
+}
+TG_DEV float tg_atomic_add(float* p, float v) { float o = *p; *p = o + v; return o; }
+#else
+// ------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define TG_KERNEL __global__
+#define TG_DEV __device__ __forceinline__
+#define TG_DEVM __device__ __forceinline__
+#define TG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+// all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned
+// (cdna_hip_programming.md Guideline 17; a second __shared__ object de-pipelines, section 5 trap 4a)
+#define TG_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char tg_lds[]
+typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
+TG_DEV float tg_exp(float x) { return __expf(x); }
+TG_DEV float tg_log(float x) { return __logf(x); }
+TG_DEV float tg_rcp(float x) { return __frcp_rn(x); }
+TG_DEV float tg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+TG_DEV int tg_lane() { return threadIdx.x & 63; }
+TG_DEV int tg_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+TG_DEV unsigned tg_pack_bf16(float lo, float hi) {        // -> v_cvt_pk_bf16_f32 (RNE)
+    tg_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][col=l&15];
+// D: lane l, reg r -> row = 4*(l>>4)+r, col = l&15.
+TG_DEV f32x4 tg_mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tg_bf16x8, a), __builtin_bit_cast(tg_bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x4_f32: lane l holds A[row=l&15][k=l>>4], B[k=l>>4][col=l&15]; exact f32 fmaf chain.
+TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+TG_DEV float tg_atomic_add(float* p, float v) { return atomicAdd(p, v); }
+#endif
+
+TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }
+TG_DEV float tg_bf16_hi_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }
+TG_DEV float tg_fmax(float a, float b) { return a > b ? a : b; }
+
+// ----------------------------------------------------------------------------------------------
+// GEMM operand precision policies.  Every operand tile row in LDS is 128 bytes = 8 chunks of
+// 16 bytes; a chunk is the unit a lane feeds to the matrix core (8 bf16 or 4 f32 along the
+// contraction axis).  Lane (row = l&15, g = l>>4) reads chunk 4q+g, q = 0,1; the contraction
+// index order inside a tile row is irrelevant as long as A and B agree, which they do.
+//   PrecF32   : exact f32 MFMA (v_mfma_f32_16x16x4_f32), 4 per chunk pair.      32 elements / row
+//   PrecBF16  : operands rounded to bf16, f32 accumulate.                        64 elements / row
+//   PrecBF16x3: operands split hi+lo bf16, a*b ~ ah*bh + ah*bl + al*bh, f32 acc  64 elements / row
+// ----------------------------------------------------------------------------------------------
+struct PrecF32 {
+    static constexpr int kId = 0, NS = 1, CH = 4, BKE = 32, ESZ = 4;
+    TG_DEVM static void cvt(const float (&x)[4], u32x4& hi, u32x4& lo) {
+        hi = u32x4{__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
+                   __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
+        lo = hi;
+    }
+    TG_DEVM static f32x4 mma(const u32x4* a, const u32x4* b, f32x4 c) {
+        const f32x4 af = __builtin_bit_cast(f32x4, a[0]), bf = __builtin_bit_cast(f32x4, b[0]);
+        c = tg_mma_f32(af[0], bf[0], c);
+        c = tg_mma_f32(af[1], bf[1], c);
+        c = tg_mma_f32(af[2], bf[2], c);
+        c = tg_mma_f32(af[3], bf[3], c);
+        return c;
+    }
+};
+
+struct PrecBF16 {
+    static constexpr int kId = 1, NS = 1, CH = 8, BKE = 64, ESZ = 2;
+    TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
+        hi = u32x4{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3]), tg_pack_bf16(x[4], x[5]), tg_pack_bf16(x[6], x[7])};
+        lo = hi;
+    }
+    TG_DEVM static f32x4 mma(const u32x4* a, const u32x4* b, f32x4 c) { return tg_mma_bf16(a[0], b[0], c); }
+};
+
+struct PrecBF16x3 {
+    static constexpr int kId = 2, NS = 2, CH = 8, BKE = 64, ESZ = 2;
+    TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned p = tg_pack_bf16(x[2 * j], x[2 * j + 1]);
+            hi[j] = p;
+            r[2 * j] = x[2 * j] - tg_bf16_lo_to_f32(p);
+            r[2 * j + 1] = x[2 * j + 1] - tg_bf16_hi_to_f32(p);
+        }
+        lo = u32x4{tg_pack_bf16(r[0], r[1]), tg_pack_bf16(r[2], r[3]), tg_pack_bf16(r[4], r[5]), tg_pack_bf16(r[6], r[7])};
+    }
+    TG_DEVM static f32x4 mma(const u32x4* a, const u32x4* b, f32x4 c) {
+        c = tg_mma_bf16(a[1], b[0], c);      // small terms first
+        c = tg_mma_bf16(a[0], b[1], c);
+        c = tg_mma_bf16(a[0], b[0], c);
+        return c;
+    }
+};
+
+// XOR swizzle of the 16-byte chunk index inside a 128-byte LDS tile row: ds_read_b128 of 16
+// consecutive rows at one logical chunk touches all 16 slots of the two 256-byte bank rows.
+TG_DEV int tg_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }

@@ -1,0 +1,815 @@
+// tg_kernels.h -- hand-written gfx950 kernels for one Tangram mapping iteration.
+//
+// Math (reference tangram/mapping_optimizer.py:189-309, :358-408):
+//   P = softmax(M, axis=1)            C x V      (:201)
+//   Ghat = P^T [S | 1]                V x Kp     (:202; the extra "ones" column yields sum_c P_cv, :217)
+//   gv = mean_k cos(Ghat[:,k], G[:,k]); vg = mean_v cos(Ghat[v,:], G[v,:]); KL(d || colsum/C)   (:205-221)
+//   dGhat = d(loss)/dGhat             V x Kp
+//   X = S dGhat^T                     C x V      (autograd of :202)
+//   dP = X + a_v w_c - lambda_r (log P + 1) ; r_c = sum_v P dP ; dM = P (dP - r) + l1/l2 terms
+//   Adam(M, dM)                                   (:373,:396)
+//
+// Kernel map (one iteration = 9 launches, no host synchronisation):
+//   tg_fwd_kernel        softmax-apply fused into the A-operand load of the MFMA GEMM P^T S (split over C)
+//   tg_ghat_reduce       sum the C-splits, per-gene / per-voxel cosine statistics partials
+//   tg_gene_reduce       deterministic second stage of the per-gene statistics
+//   tg_loss_finalize     cos/KL scalars -> history row, alpha_k/beta_k, a_v
+//   tg_dghat_emit        dGhat in matrix-core operand format
+//   tg_bwd_kernel<1>     MFMA GEMM S dGhat^T fused with softmax-backward row dots r_c (partials)
+//   tg_rowsum_parts      r_c = sum of partials (+ entropy / L1 / L2 scalars into the history row)
+//   tg_bwd_kernel<2>     GEMM recomputed, fused with softmax backward + Adam + next-iteration softmax statistics
+//   tg_merge_stats       (max, sum exp) partials -> per-row shift and 1/Z for the next forward
+//
+// Data layout in HBM: M, Adam m, Adam v are C x Vp fp32 row-major (Vp = V rounded up to 64);
+// S is kept twice in operand format: St [Kp][Cp] (cell index contiguous, for the forward contraction
+// over cells) and Sk [Cr][Kp] (gene index contiguous, for the backward contraction over genes).
+#pragma once
+#include "tg_device.h"
+
+#define TG_NEG_BIG (-3.0e38f)
+#define TG_COS_EPS 1e-8f
+
+// history row layout (floats)
+enum { TGH_TOTAL = 0, TGH_MAIN, TGH_VG, TGH_KL, TGH_ENTROPY, TGH_L1, TGH_L2, TGH_NB, TGH_CT, TGH_COUNT, TGH_FREG,
+       TGH_NTERMS = 16 };
+
+// ----------------------------------------------------------------------------------------------
+// shared GEMM tile machinery: 128 x 128 output tile, 256 threads = 4 waves as 2 x 2, each wave
+// 64 x 64 = 4 x 4 MFMA 16x16 fragments.  One LDS stage = NS x {A tile, B tile}, each tile
+// 128 rows x 8 chunks (16 B) with the XOR swizzle of tg_swz.
+// ----------------------------------------------------------------------------------------------
+#define TG_TILE 128
+#define TG_TILE_CHUNKS (TG_TILE * 8)
+
+template <class PR>
+struct TgStage {
+    static constexpr int kChunks = PR::NS * 2 * TG_TILE_CHUNKS;     // u32x4 units
+    static constexpr int kBytes = kChunks * 16;
+};
+
+template <class PR>
+TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ch = 4 * q + g;
+        u32x4 a[4][PR::NS], b[4][PR::NS];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int ra = wm * 64 + f * 16 + r;
+            const int rb = wn * 64 + f * 16 + r;
+#pragma unroll
+            for (int p = 0; p < PR::NS; ++p) {
+                a[f][p] = st[(p * 2 + 0) * TG_TILE_CHUNKS + ra * 8 + tg_swz(ra, ch)];
+                b[f][p] = st[(p * 2 + 1) * TG_TILE_CHUNKS + rb * 8 + tg_swz(rb, ch)];
+            }
+        }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj) acc[fi][fj] = PR::mma(a[fi], b[fj], acc[fi][fj]);
+    }
+}
+
+// a 128-row x 128-byte tile of an operand whose contraction axis is contiguous in memory
+template <class PR>
+struct TgKTile {
+    u32x4 v[PR::NS][4];
+    TG_DEVM void load(const unsigned char* const (&base)[2], size_t row0, size_t pitch_bytes, size_t byte0, int t) {
+        const int chunk = t & 7;
+#pragma unroll
+        for (int p = 0; p < PR::NS; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (t >> 3) + 32 * i;
+                v[p][i] = *(const u32x4*)(base[p] + (row0 + row) * pitch_bytes + byte0 + chunk * 16);
+            }
+    }
+    TG_DEVM void store(u32x4* st, int which, int t) const {
+        const int chunk = t & 7;
+#pragma unroll
+        for (int p = 0; p < PR::NS; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (t >> 3) + 32 * i;
+                st[(p * 2 + which) * TG_TILE_CHUNKS + row * 8 + tg_swz(row, chunk)] = v[p][i];
+            }
+    }
+};
+
+// ----------------------------------------------------------------------------------------------
+// K1: Ghat_partial[split] = P[c-range]^T [S|1][c-range]          (mapping_optimizer.py:201-202,:217)
+//   output tile: 128 spots x 128 genes; contraction over cells in steps of PR::BKE.
+//   A operand (P^T) is produced on the fly: CH x 4 micro-blocks of M are loaded as float4 rows,
+//   exponentiated with the per-row shift/scale, transposed in registers and written to LDS
+//   as 16-byte chunks along the cell axis.  B operand comes from St (cell axis contiguous).
+// ----------------------------------------------------------------------------------------------
+struct TgFwdArgs {
+    const float* M;
+    const float* rshift;     // [Cp] per-row softmax shift (row max); padding = +3e38
+    const float* rscale;     // [Cp] per-row scale 1/Z (times the filter f_c in constrained mode); padding = 0
+    const unsigned char* St[2];
+    float* Gpart;            // [nsplit][Vr][Kp]
+    int C, V, Vp, Vr, Kp, Cp;
+    int nkt;                 // gene tiles (Kp / 128)
+    int nsteps;              // Cp / BKE
+};
+
+template <class PR>
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
+    TG_LDS_DECL;
+    u32x4* lds = (u32x4*)tg_lds;
+    const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int vt = blockIdx.x / a.nkt, kt = blockIdx.x % a.nkt;
+    const int v0 = vt * TG_TILE, k0 = kt * TG_TILE;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int s_begin = (int)(((long long)a.nsteps * split) / nsplit);
+    const int s_end = (int)(((long long)a.nsteps * (split + 1)) / nsplit);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A staging: thread = (spot quad, cell chunk)
+    const int quad = t & 31, chk = t >> 5;
+    const int vcol = v0 + 4 * quad;
+    const int vload = (vcol < a.Vp) ? vcol : 0;
+    bool vok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vok[i] = (vcol + i) < a.V;
+
+    f32x4 mreg[PR::CH];
+    float sh[PR::CH], sc[PR::CH];
+    TgKTile<PR> breg;
+
+    auto load_stage = [&](int step) {
+        const int cb = step * PR::BKE + chk * PR::CH;
+#pragma unroll
+        for (int j = 0; j < PR::CH; ++j) {
+            const int c = cb + j;
+            const int cc = c < a.C ? c : a.C - 1;
+            mreg[j] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + vload);
+            sh[j] = a.rshift[c];
+            sc[j] = a.rscale[c];
+        }
+        breg.load(a.St, (size_t)k0, (size_t)a.Cp * PR::ESZ, (size_t)step * PR::BKE * PR::ESZ, t);
+    };
+    auto store_stage = [&](u32x4* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x[PR::CH];
+#pragma unroll
+            for (int j = 0; j < PR::CH; ++j) {
+                const float p = tg_exp(mreg[j][i] - sh[j]) * sc[j];
+                x[j] = vok[i] ? p : 0.f;
+            }
+            u32x4 hi, lo;
+            PR::cvt(x, hi, lo);
+            const int row = 4 * quad + i;
+            st[0 * TG_TILE_CHUNKS + row * 8 + tg_swz(row, chk)] = hi;
+            if (PR::NS == 2) st[2 * TG_TILE_CHUNKS + row * 8 + tg_swz(row, chk)] = lo;
+        }
+        breg.store(st, 1, t);
+    };
+
+    if (s_begin < s_end) {
+        load_stage(s_begin);
+        store_stage(lds);
+        __syncthreads();
+        for (int s = s_begin; s < s_end; ++s) {
+            u32x4* cur = lds + ((s - s_begin) & 1) * TgStage<PR>::kChunks;
+            u32x4* nxt = lds + ((s - s_begin + 1) & 1) * TgStage<PR>::kChunks;
+            const bool more = (s + 1) < s_end;
+            if (more) load_stage(s + 1);            // global loads in flight under the MFMAs
+            tg_tile_mma<PR>(cur, wm, wn, lane, acc);
+            if (more) store_stage(nxt);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane holds 4 consecutive spots (regs) x 1 gene (lane&15) per fragment
+    float* out = a.Gpart + (size_t)split * a.Vr * a.Kp;
+    const int g = lane >> 4, r15 = lane & 15;
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj) {
+            const int v = v0 + wm * 64 + fi * 16 + 4 * g;
+            const int k = k0 + wn * 64 + fj * 16 + r15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(v + r) * a.Kp + k] = acc[fi][fj][r];
+        }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K2a: sum C-splits -> Ghat, per-gene partial sums over a block of spots, per-spot sums over genes
+//   (cosine_similarity statistics, mapping_optimizer.py:205-206)
+// ----------------------------------------------------------------------------------------------
+#define TG_RB 16   // spots per block in the V x Kp elementwise kernels
+
+struct TgGhatReduceArgs {
+    const float* Gpart; int nsplit;
+    const float* G;            // [Vr][Kp] fp32, zero padded
+    float* Ghat;               // [Vr][Kp]
+    float* genepart;           // [nrb][2][Kp]  (dot, |Ghat|^2)
+    float* voxstat;            // [2][Vr] (dot_v, |Ghat_v|^2) over genes k < K; written iff want_vox
+    int V, Vr, Kp, K, want_vox;
+};
+
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;     // [4 waves][TG_RB][2]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int rb = blockIdx.x;
+    const int vbeg = rb * TG_RB;
+    const int nk4 = a.Kp >> 2;
+    float vd[TG_RB], vn[TG_RB];
+#pragma unroll
+    for (int i = 0; i < TG_RB; ++i) vd[i] = vn[i] = 0.f;
+    for (int c4 = t; c4 < nk4; c4 += 256) {
+        f32x4 gd = {0, 0, 0, 0}, gn = {0, 0, 0, 0};
+        const int k = c4 * 4;
+#pragma unroll
+        for (int i = 0; i < TG_RB; ++i) {
+            const int v = vbeg + i;
+            if (v < a.V) {
+                const size_t off = (size_t)v * a.Kp + k;
+                f32x4 s = *(const f32x4*)(a.Gpart + off);
+                for (int p = 1; p < a.nsplit; ++p) s += *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
+                *(f32x4*)(a.Ghat + off) = s;
+                const f32x4 g = *(const f32x4*)(a.G + off);
+                gd += s * g;
+                gn += s * s;
+                if (a.want_vox) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < a.K) { vd[i] += s[e] * g[e]; vn[i] += s[e] * s[e]; }
+                }
+            }
+        }
+        *(f32x4*)(a.genepart + ((size_t)rb * 2 + 0) * a.Kp + k) = gd;
+        *(f32x4*)(a.genepart + ((size_t)rb * 2 + 1) * a.Kp + k) = gn;
+    }
+    if (a.want_vox) {
+#pragma unroll
+        for (int i = 0; i < TG_RB; ++i) {
+            float d = vd[i], n = vn[i];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { d += tg_shfl_xor(d, m); n += tg_shfl_xor(n, m); }
+            if (lane == 0) { red[(wave * TG_RB + i) * 2 + 0] = d; red[(wave * TG_RB + i) * 2 + 1] = n; }
+        }
+        __syncthreads();
+        if (t < TG_RB && vbeg + t < a.V) {
+            float d = 0.f, n = 0.f;
+            for (int w = 0; w < 4; ++w) { d += red[(w * TG_RB + t) * 2 + 0]; n += red[(w * TG_RB + t) * 2 + 1]; }
+            a.voxstat[vbeg + t] = d;
+            a.voxstat[a.Vr + vbeg + t] = n;
+        }
+    }
+}
+
+// K2b: second stage of the per-gene sums (fixed order => deterministic)
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Kp) return;
+    float d = 0.f, n = 0.f;
+    for (int b = 0; b < nrb; ++b) {
+        d += genepart[((size_t)b * 2 + 0) * Kp + k];
+        n += genepart[((size_t)b * 2 + 1) * Kp + k];
+    }
+    genestat[k] = d;
+    genestat[Kp + k] = n;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K2c: scalars + gradient coefficients.  One block of 1024 threads.
+//   gv (:205,:208), vg (:206,:209), KL (:212-219), total (:266-270) -> history row
+//   alpha_k, beta_k:  dGhat_vk (gene term)  = alpha_k G_vk + beta_k Ghat_vk
+//   va_v, vb_v:       dGhat_vk (voxel term) = va_v G_vk + vb_v Ghat_vk
+//   a_v = -lambda_d d_v / colsum_v   (dP_cv += a_v w_c)
+// In a spot-sharded multi-GPU run genestat/gnorm2 hold globally reduced values while the per-spot
+// sums are local; `nranks_v` and V_total make the means global.
+// ----------------------------------------------------------------------------------------------
+struct TgFinalizeArgs {
+    const float* genestat;     // [2][Kp] (dot_k, |Ghat_k|^2) (global)
+    const float* gnorm2;       // [Kp] |G_k|^2 (global)
+    const float* Ghat;         // [Vr][Kp] (aug column K = colsum)
+    const float* voxstat;      // [2][Vr]
+    const float* vnorm2;       // [Vr] |G_v|^2 over genes
+    const float* d;            // [Vr] density prior or null
+    float* coef;               // [2][Kp] alpha, beta
+    float* vcoef;              // [3][Vr] va, vb, a_v
+    float* hist;               // history row [TGH_NTERMS]
+    float lambda_g1, lambda_g2, lambda_d;
+    float rho_scale;           // 1/C for a uniform source, 1 for d_source (rho_v = colsum_v * rho_scale)
+    int K, Kp, V, Vr, V_total, has_density;
+};
+
+TG_DEV float tg_block_sum_1024(float x, float* red) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += tg_shfl_xor(x, m);
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    float s = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    return s;
+}
+
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    const int t = threadIdx.x;
+    float cs = 0.f;
+    for (int k = t; k < a.Kp; k += 1024) {
+        float al = 0.f, be = 0.f;
+        if (k < a.K) {
+            const float dot = a.genestat[k];
+            const float na = tg_fmax(sqrtf(a.genestat[a.Kp + k]), TG_COS_EPS);
+            const float nb = tg_fmax(sqrtf(a.gnorm2[k]), TG_COS_EPS);
+            const float c = dot / (na * nb);
+            cs += c;
+            const float w = a.lambda_g1 / (float)a.K;
+            al = -w / (na * nb);
+            be = w * c / (na * na);
+        }
+        a.coef[k] = al;
+        a.coef[a.Kp + k] = be;
+    }
+    const float gv = tg_block_sum_1024(cs, red) / (float)a.K;
+
+    float vs = 0.f, kl = 0.f;
+    for (int v = t; v < a.Vr; v += 1024) {
+        float va = 0.f, vb = 0.f, av = 0.f;
+        if (v < a.V) {
+            if (a.lambda_g2 != 0.f) {
+                const float dot = a.voxstat[v];
+                const float na = tg_fmax(sqrtf(a.voxstat[a.Vr + v]), TG_COS_EPS);
+                const float nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
+                const float c = dot / (na * nb);
+                vs += c;
+                const float w = a.lambda_g2 / (float)a.V_total;
+                va = -w / (na * nb);
+                vb = w * c / (na * na);
+            }
+            if (a.has_density) {
+                const float colsum = a.Ghat[(size_t)v * a.Kp + a.K];
+                const float dv = a.d[v];
+                const float rho = colsum * a.rho_scale;
+                if (dv != 0.f) kl += dv * (tg_log(dv) - tg_log(rho));   // KLDivLoss(sum): xlogy(d,d) - d*log(rho)
+                av = -a.lambda_d * dv * a.rho_scale / rho;              // = -lambda_d d_v / colsum_v
+            }
+        }
+        a.vcoef[v] = va;
+        a.vcoef[a.Vr + v] = vb;
+        a.vcoef[2 * a.Vr + v] = av;
+    }
+    const float vg = tg_block_sum_1024(vs, red) / (float)a.V_total;
+    const float klsum = tg_block_sum_1024(kl, red);
+    if (t == 0) {
+        const float nanv = __builtin_nanf("");
+        float total = -a.lambda_g1 * gv;
+        if (a.lambda_g2 != 0.f) total -= a.lambda_g2 * vg;
+        if (a.has_density) total += a.lambda_d * klsum;
+        for (int i = 0; i < TGH_NTERMS; ++i) a.hist[i] = nanv;
+        a.hist[TGH_TOTAL] = total;
+        a.hist[TGH_MAIN] = gv;
+        a.hist[TGH_VG] = (a.lambda_g2 != 0.f) ? vg : nanv;        // reference: 0*x/0 = nan (:209)
+        a.hist[TGH_KL] = a.has_density ? klsum : nanv;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K2d: dGhat in operand format (contraction axis = genes contiguous), rows = spots
+// ----------------------------------------------------------------------------------------------
+struct TgEmitArgs {
+    const float* Ghat; const float* G; const float* coef; const float* vcoef;
+    unsigned char* dG[2];      // [Vr][Kp] operand elements
+    int V, Vr, Kp, K;
+};
+
+template <class PR>
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
+    const int nch = a.Kp / PR::CH;
+    const int vbeg = blockIdx.x * TG_RB;
+    for (int idx = threadIdx.x; idx < nch * TG_RB; idx += 256) {
+        const int i = idx / nch, ch = idx % nch;
+        const int v = vbeg + i;
+        if (v >= a.V) continue;
+        const int k = ch * PR::CH;
+        const float va = a.vcoef[v], vb = a.vcoef[a.Vr + v];
+        float x[PR::CH];
+#pragma unroll
+        for (int e = 0; e < PR::CH; ++e) {
+            const size_t off = (size_t)v * a.Kp + k + e;
+            const float gh = a.Ghat[off], g = a.G[off];
+            const float val = (a.coef[k + e] + va) * g + (a.coef[a.Kp + k + e] + vb) * gh;
+            x[e] = (k + e < a.K) ? val : 0.f;
+        }
+        u32x4 hi, lo;
+        PR::cvt(x, hi, lo);
+        const size_t boff = ((size_t)v * a.Kp + k) * PR::ESZ;
+        *(u32x4*)(a.dG[0] + boff) = hi;
+        if (PR::NS == 2) *(u32x4*)(a.dG[1] + boff) = lo;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K3: X^T tile = dGhat[v-tile] . S[c-tile]^T  (contraction over genes), fused epilogues.
+//   PHASE 1: r_part[vt][c] = sum_{v in tile} P_cv dP_cv                  (softmax backward row dot)
+//            + row partials of the entropy / L1 / L2 scalars
+//   PHASE 2: dM = P (dP - r_c) [+ l1 sign(M) + 2 l2 M]; Adam; store M, m, v;
+//            (max, sum exp) partials of the NEW row for the next forward pass
+//   Fragment ownership: lane holds 4 consecutive spots (float4 of M) for cell c = lane&15.
+// ----------------------------------------------------------------------------------------------
+struct TgBwdArgs {
+    const unsigned char* dG[2];   // A operand [Vr][Kp]
+    const unsigned char* Sk[2];   // B operand [Cr][Kp]
+    float* M; float* am; float* av;                // logits and Adam moments, pitch Vp
+    const float* rshift; const float* rinvz;       // [Cp] softmax shift and 1/Z of the CURRENT M
+    const float* fgate;                            // [C] filter f_c (constrained) or null
+    const float* vcoef;                            // a_v at [2*Vr + v]
+    const float* dens_w;                           // [C] w_c (d_source) or null (=1)
+    const float* r;                                // [C] (phase 2)
+    float* part;                                   // phase 1: [nvt][NP1][C]; phase 2: [nvt][2][C]
+    int C, V, Vp, Vr, Kp, nct;
+    float lambda_r, lambda_l1, lambda_l2;
+    float step_size, bc2_sqrt, beta1, beta2, eps;  // Adam (phase 2)
+};
+enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
+
+template <class PR, int PHASE, bool FULL>
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_bwd_kernel(TgBwdArgs a) {
+    TG_LDS_DECL;
+    u32x4* lds = (u32x4*)tg_lds;
+    const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int vt = blockIdx.x / a.nct, ct = blockIdx.x % a.nct;
+    const int v0 = vt * TG_TILE, c0 = ct * TG_TILE;
+    const int nsteps = a.Kp / PR::BKE;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TgKTile<PR> ra, rb;
+    const size_t pitch = (size_t)a.Kp * PR::ESZ;
+    ra.load(a.dG, (size_t)v0, pitch, 0, t);
+    rb.load(a.Sk, (size_t)c0, pitch, 0, t);
+    ra.store(lds, 0, t);
+    rb.store(lds, 1, t);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        u32x4* cur = lds + (s & 1) * TgStage<PR>::kChunks;
+        u32x4* nxt = lds + ((s + 1) & 1) * TgStage<PR>::kChunks;
+        const bool more = (s + 1) < nsteps;
+        if (more) {
+            const size_t b0 = (size_t)(s + 1) * PR::BKE * PR::ESZ;
+            ra.load(a.dG, (size_t)v0, pitch, b0, t);
+            rb.load(a.Sk, (size_t)c0, pitch, b0, t);
+        }
+        tg_tile_mma<PR>(cur, wm, wn, lane, acc);
+        if (more) { ra.store(nxt, 0, t); rb.store(nxt, 1, t); }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    float* red = (float*)tg_lds;        // reuse LDS (all waves are past the last barrier)
+    const int g = lane >> 4, r15 = lane & 15;
+    constexpr int NP = (PHASE == 1) ? (FULL ? (int)TGP1_N : 1) : 2;
+    float pacc[4][NP];
+
+#pragma unroll
+    for (int fj = 0; fj < 4; ++fj) {
+        const int c = c0 + wn * 64 + fj * 16 + r15;
+        const bool cok = c < a.C;
+        const int cc = cok ? c : a.C - 1;
+        const float sh = a.rshift[cc], iz = a.rinvz[cc];
+        const float fg = a.fgate ? a.fgate[cc] : 1.f;
+        const float wc = a.dens_w ? a.dens_w[cc] : 1.f;
+        if constexpr (PHASE == 1) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) pacc[fj][q] = 0.f;
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const int v = v0 + wm * 64 + fi * 16 + 4 * g;
+                if (v >= a.Vp) continue;
+                const f32x4 mq = *(const f32x4*)(a.M + (size_t)cc * a.Vp + v);
+                const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (cok && (v + e) < a.V) {
+                        const float p = tg_exp(mq[e] - sh) * iz;
+                        const float x = acc[fi][fj][e];
+                        float dp = fg * (x + aq[e] * wc);
+                        if (FULL) {
+                            if (a.lambda_r != 0.f) {
+                                const float lp = (mq[e] - sh) + tg_log(iz);      // log P, no underflow
+                                dp -= a.lambda_r * (lp + 1.f);
+                                pacc[fj][TGP1_ENT % NP] += p * lp;
+                            }
+                            pacc[fj][TGP1_Q % NP] += p * x;
+                            pacc[fj][TGP1_PA % NP] += p * aq[e];
+                            pacc[fj][TGP1_L1 % NP] += fabsf(mq[e]);
+                            pacc[fj][TGP1_L2 % NP] += mq[e] * mq[e];
+                        }
+                        pacc[fj][TGP1_R] += p * dp;
+                    }
+                }
+            }
+        } else {
+            const float rc = a.r[cc];
+            float nm[16];
+            float lmax = TG_NEG_BIG;
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const int v = v0 + wm * 64 + fi * 16 + 4 * g;
+                const bool qok = cok && (v < a.Vp);
+                const size_t off = (size_t)cc * a.Vp + (qok ? v : 0);
+                f32x4 mq = *(const f32x4*)(a.M + off);
+                f32x4 m1 = *(const f32x4*)(a.am + off);
+                f32x4 m2 = *(const f32x4*)(a.av + off);
+                const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = qok && (v + e) < a.V;
+                    const float mo = mq[e];
+                    const float p = tg_exp(mo - sh) * iz;
+                    float dp = fg * (acc[fi][fj][e] + aq[e] * wc);
+                    if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + tg_log(iz) + 1.f);
+                    float gm = p * (dp - rc);
+                    if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
+                    if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
+                    // torch.optim.Adam (_single_tensor_adam): lerp, mul+addcmul, sqrt/bc2 + eps, addcdiv
+                    const float e1 = m1[e] + (gm - m1[e]) * (1.f - a.beta1);
+                    const float e2 = m2[e] * a.beta2 + (1.f - a.beta2) * gm * gm;
+                    const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
+                    const float mn = mo - a.step_size * (e1 / den);
+                    if (ok) { mq[e] = mn; m1[e] = e1; m2[e] = e2; lmax = tg_fmax(lmax, mn); }
+                    nm[fi * 4 + e] = ok ? mn : TG_NEG_BIG;
+                }
+                if (qok) {
+                    *(f32x4*)(a.M + off) = mq;
+                    *(f32x4*)(a.am + off) = m1;
+                    *(f32x4*)(a.av + off) = m2;
+                }
+            }
+            float lsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lsum += (nm[i] > TG_NEG_BIG) ? tg_exp(nm[i] - lmax) : 0.f;
+            pacc[fj][0] = lmax;
+            pacc[fj][1] = lsum;
+        }
+        // reduce over the 4 lane groups holding the same cell (different spots)
+        if constexpr (PHASE == 1) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                float x = pacc[fj][q];
+                x += tg_shfl_xor(x, 16);
+                x += tg_shfl_xor(x, 32);
+                pacc[fj][q] = x;
+            }
+        } else {
+#pragma unroll
+            for (int msk = 16; msk <= 32; msk <<= 1) {
+                const float om = tg_shfl_xor(pacc[fj][0], msk), os = tg_shfl_xor(pacc[fj][1], msk);
+                const float nmx = tg_fmax(pacc[fj][0], om);
+                pacc[fj][1] = pacc[fj][1] * tg_exp(pacc[fj][0] - nmx) + os * tg_exp(om - nmx);
+                pacc[fj][0] = nmx;
+            }
+        }
+    }
+    // combine the two waves along the spot axis through LDS, then one store per cell
+    __syncthreads();                       // all MFMA reads of LDS are done before reuse
+    if (g == 0) {
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) red[((wm * NP + q) * TG_TILE) + wn * 64 + fj * 16 + r15] = pacc[fj][q];
+    }
+    __syncthreads();
+    if (t < TG_TILE) {
+        const int c = c0 + t;
+        if (c < a.C) {
+            if constexpr (PHASE == 1) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    a.part[((size_t)vt * NP + q) * a.C + c] = red[(0 * NP + q) * TG_TILE + t] + red[(1 * NP + q) * TG_TILE + t];
+            } else {
+                const float m0 = red[(0 * NP + 0) * TG_TILE + t], s0 = red[(0 * NP + 1) * TG_TILE + t];
+                const float m1 = red[(1 * NP + 0) * TG_TILE + t], s1 = red[(1 * NP + 1) * TG_TILE + t];
+                const float mx = tg_fmax(m0, m1);
+                a.part[((size_t)vt * 2 + 0) * a.C + c] = mx;
+                a.part[((size_t)vt * 2 + 1) * a.C + c] = s0 * tg_exp(m0 - mx) + s1 * tg_exp(m1 - mx);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// small per-row kernels
+// ----------------------------------------------------------------------------------------------
+// r_c = sum over spot tiles of the phase-1 partials; also the scalar regulariser sums
+struct TgRowsumArgs {
+    const float* part; int nvt; int C; int np;
+    float* rowq;               // [np][C] summed partials (row 0 = r_c)
+};
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    for (int q = 0; q < a.np; ++q) {
+        float s = 0.f;
+        for (int p = 0; p < a.nvt; ++p) s += a.part[((size_t)p * a.np + q) * a.C + c];
+        a.rowq[(size_t)q * a.C + c] = s;
+    }
+}
+
+// entropy / L1 / L2 scalars (mapping_optimizer.py:224-231) from the per-row sums -> history row
+struct TgHistRegArgs { const float* rowq; int C; float* hist; float lambda_r, lambda_l1, lambda_l2; };
+
+// deterministic sum of a [n] vector into out[0] (single block)
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_vec_sum(const float* x, int n, float* out, float scale, int accumulate) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = tg_block_sum_1024(s, red);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s;
+}
+
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs(TgHistRegArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    float e = 0.f, l1 = 0.f, l2 = 0.f;
+    for (int c = threadIdx.x; c < a.C; c += 1024) {
+        e += a.rowq[(size_t)TGP1_ENT * a.C + c];
+        l1 += a.rowq[(size_t)TGP1_L1 * a.C + c];
+        l2 += a.rowq[(size_t)TGP1_L2 * a.C + c];
+    }
+    e = tg_block_sum_1024(e, red);
+    l1 = tg_block_sum_1024(l1, red);
+    l2 = tg_block_sum_1024(l2, red);
+    if (threadIdx.x == 0) {
+        float total = a.hist[TGH_TOTAL];
+        if (a.lambda_r != 0.f) { a.hist[TGH_ENTROPY] = -e; total += a.lambda_r * (-e); }
+        if (a.lambda_l1 != 0.f) { a.hist[TGH_L1] = l1; total += a.lambda_l1 * l1; }
+        if (a.lambda_l2 != 0.f) { a.hist[TGH_L2] = l2; total += a.lambda_l2 * l2; }
+        a.hist[TGH_TOTAL] = total;
+    }
+}
+
+// merge (max, sum exp) partials over `nparts` -> rshift = max, rinvz = 1/Z ; optional raw output
+struct TgMergeArgs {
+    const float* part;         // [nparts][2][C]
+    int nparts, C;
+    float* rshift; float* rinvz;       // final (may be null when only the local pair is wanted)
+    float* pair_out;           // [2][C] local (max, Z) for the cross-GPU exchange, or null
+    const float* fgate; float* rscale; // rscale = rinvz * f_c (or = rinvz)
+};
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    float mx = TG_NEG_BIG;
+    for (int p = 0; p < a.nparts; ++p) mx = tg_fmax(mx, a.part[((size_t)p * 2 + 0) * a.C + c]);
+    float z = 0.f;
+    for (int p = 0; p < a.nparts; ++p)
+        z += a.part[((size_t)p * 2 + 1) * a.C + c] * tg_exp(a.part[((size_t)p * 2 + 0) * a.C + c] - mx);
+    if (a.pair_out) { a.pair_out[c] = mx; a.pair_out[a.C + c] = z; }
+    if (a.rshift) {
+        const float iz = 1.f / z;
+        a.rshift[c] = mx;
+        a.rinvz[c] = iz;
+        a.rscale[c] = a.fgate ? iz * a.fgate[c] : iz;
+    }
+}
+
+// one block per row: (max, sum exp) of a row of M (initialisation / fallback path)
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_row_stats(const float* M, int C, int V, int Vp, float* part /*[1][2][C]*/) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* row = M + (size_t)c * Vp;
+    float mx = TG_NEG_BIG;
+    for (int v = t; v < V; v += 256) mx = tg_fmax(mx, row[v]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = tg_fmax(mx, tg_shfl_xor(mx, m));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = tg_fmax(tg_fmax(red[0], red[1]), tg_fmax(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int v = t; v < V; v += 256) s += tg_exp(row[v] - mx);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += tg_shfl_xor(s, m);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (t == 0) { part[c] = mx; part[C + c] = red[0] + red[1] + red[2] + red[3]; }
+}
+
+// P_out[c][v] = softmax(M)[c][v]  (mapping_optimizer.py:407), dense pitch V; one block per cell
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_softmax_out(const float* M, const float* rshift, const float* rinvz,
+                                                    int C, int V, int Vp, float* out) {
+    const int c = blockIdx.x;
+    const float sh = rshift[c], iz = rinvz[c];
+    for (int v = threadIdx.x; v < V; v += 256) out[(size_t)c * V + v] = tg_exp(M[(size_t)c * Vp + v] - sh) * iz;
+}
+
+// ----------------------------------------------------------------------------------------------
+// set-up kernels: operand images of S and the padded fp32 copy of G
+// ----------------------------------------------------------------------------------------------
+struct TgPrepSArgs {
+    const float* S; int C, K;           // caller's [C][K]
+    const float* aug;                   // [C] values of the augmentation column (null => 1)
+    unsigned char* Sk[2]; int Cr, Kp;   // [Cr][Kp]
+    unsigned char* St[2]; int Cp;       // [Kp][Cp]
+};
+TG_DEV float tg_s_aug(const TgPrepSArgs& a, int c, int k) {
+    if (c >= a.C) return 0.f;
+    if (k < a.K) return a.S[(size_t)c * a.K + k];
+    if (k == a.K) return a.aug ? a.aug[c] : 1.f;
+    return 0.f;
+}
+template <class PR>
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_sk(TgPrepSArgs a) {
+    const int nch = a.Kp / PR::CH;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)a.Cr * nch) return;
+    const int c = (int)(idx / nch), ch = (int)(idx % nch);
+    float x[PR::CH];
+#pragma unroll
+    for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, c, ch * PR::CH + e);
+    u32x4 hi, lo;
+    PR::cvt(x, hi, lo);
+    const size_t boff = ((size_t)c * a.Kp + (size_t)ch * PR::CH) * PR::ESZ;
+    *(u32x4*)(a.Sk[0] + boff) = hi;
+    if (PR::NS == 2) *(u32x4*)(a.Sk[1] + boff) = lo;
+}
+template <class PR>
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_st(TgPrepSArgs a) {
+    const int nch = a.Cp / PR::CH;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)a.Kp * nch) return;
+    const int k = (int)(idx % a.Kp), ch = (int)(idx / a.Kp);     // k fastest: coalesced reads of S rows
+    float x[PR::CH];
+#pragma unroll
+    for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, ch * PR::CH + e, k);
+    u32x4 hi, lo;
+    PR::cvt(x, hi, lo);
+    const size_t boff = ((size_t)k * a.Cp + (size_t)ch * PR::CH) * PR::ESZ;
+    *(u32x4*)(a.St[0] + boff) = hi;
+    if (PR::NS == 2) *(u32x4*)(a.St[1] + boff) = lo;
+}
+
+// Gp = zero-padded copy of G; vnorm2[v] = sum_k G^2; gnormpart[rb][k] = partial sum_v G^2
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_g(const float* G, int V, int K, int Vr, int Kp, float* Gp, float* vnorm2,
+                                               float* gnormpart /*[nrb][Kp]*/) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int vbeg = blockIdx.x * TG_RB;
+    float vn[TG_RB];
+#pragma unroll
+    for (int i = 0; i < TG_RB; ++i) vn[i] = 0.f;
+    for (int k = t; k < Kp; k += 256) {
+        float gs = 0.f;
+#pragma unroll
+        for (int i = 0; i < TG_RB; ++i) {
+            const int v = vbeg + i;
+            float x = 0.f;
+            if (v < V && k < K) x = G[(size_t)v * K + k];
+            if (v < Vr) Gp[(size_t)v * Kp + k] = x;
+            gs += x * x;
+            vn[i] += x * x;
+        }
+        gnormpart[(size_t)blockIdx.x * Kp + k] = gs;
+    }
+#pragma unroll
+    for (int i = 0; i < TG_RB; ++i) {
+        float n = vn[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) n += tg_shfl_xor(n, m);
+        if (lane == 0) red[wave * TG_RB + i] = n;
+    }
+    __syncthreads();
+    if (t < TG_RB && vbeg + t < Vr) vnorm2[vbeg + t] = red[t] + red[TG_RB + t] + red[2 * TG_RB + t] + red[3 * TG_RB + t];
+}
+
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_colsum_parts(const float* part, int nparts, int n, float* out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + k];
+    out[k] = s;
+}
+
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fill(float* p, size_t n, float val) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = val;
+}

@@ -1,0 +1,153 @@
+"""Thin owner of one `tg_mapper` handle: device buffers come from torch (plumbing), every
+computation goes through the C ABI of libtangram_hip.so."""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def _as_dev_f32(x, device):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)), device=device)
+
+
+class HipMapperEngine:
+    """State + workspace of one mapping problem (or one spot-shard of it) on one GPU."""
+
+    def __init__(self, S, G, M0, d=None, d_source=None, F0=None, *, mode="mapper", device="cuda:0",
+                 precision="bf16x3", lambdas=None, n_spots_total=None, fwd_splits=0,
+                 target_count=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" and not _capi.is_emulated():
+            raise RuntimeError(f"tangram_amd runs on a HIP device only (got device={device!r}); there is no CPU path")
+        if precision not in _capi.PRECISIONS:
+            raise ValueError(f"gemm precision must be one of {sorted(_capi.PRECISIONS)}")
+        self._lib = _capi.lib()
+        lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0,
+                   lambda_count=1.0, lambda_f_reg=1.0)
+        lam.update(lambdas or {})
+        S = _as_dev_f32(S, self.device)
+        G = _as_dev_f32(G, self.device)
+        M0 = _as_dev_f32(M0, self.device)
+        d = _as_dev_f32(d, self.device)
+        d_source = _as_dev_f32(d_source, self.device)
+        F0 = _as_dev_f32(F0, self.device)
+        self.C, self.K = S.shape
+        self.V = G.shape[0]
+        if G.shape[1] != self.K:
+            raise ValueError("S and G must have the same number of genes")
+        if tuple(M0.shape) != (self.C, self.V):
+            raise ValueError("M0 must be [n_cells, n_spots]")
+        cfg = _capi.TgConfig()
+        cfg.abi_version = _capi.TG_ABI_VERSION
+        cfg.mode = _capi.TG_MODE_CONSTRAINED if mode == "constrained" else _capi.TG_MODE_MAPPER
+        cfg.precision = _capi.PRECISIONS[precision]
+        cfg.n_cells, cfg.n_genes, cfg.n_spots = self.C, self.K, self.V
+        cfg.n_spots_total = int(n_spots_total or self.V)
+        cfg.has_density = int(d is not None)
+        cfg.has_d_source = int(d_source is not None)
+        cfg.fwd_splits = int(fwd_splits)
+        for k, v in lam.items():
+            setattr(cfg, k, float(v))
+        cfg.target_count = float(target_count)
+        cfg.beta1, cfg.beta2, cfg.eps = float(betas[0]), float(betas[1]), float(eps)
+        self.cfg = cfg
+        self.precision = precision
+        sizes = _capi.TgSizes()
+        _capi.check(self._lib.tg_query_sizes(ct.byref(cfg), ct.byref(sizes)))
+        self.sizes = sizes
+        self.state = torch.empty(sizes.state_bytes, dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
+        inp = _capi.TgInputs()
+        inp.S_dev, inp.G_dev, inp.M0_dev = S.data_ptr(), G.data_ptr(), M0.data_ptr()
+        inp.d_dev = d.data_ptr() if d is not None else None
+        inp.d_source_dev = d_source.data_ptr() if d_source is not None else None
+        inp.F0_dev = F0.data_ptr() if F0 is not None else None
+        handle = ct.c_void_p()
+        _capi.check(self._lib.tg_mapper_create(ct.byref(cfg), ct.byref(inp), self.state.data_ptr(),
+                                               self.workspace.data_ptr(), self._stream(), ct.byref(handle)))
+        self._h = handle
+        self._sync()            # inputs were only borrowed for the duration of create()
+        self._scratch_row = torch.zeros(_capi.H_NTERMS, dtype=torch.float32, device=self.device)
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _stream(self):
+        if self.device.type == "cuda":
+            return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._sync()
+            self._lib.tg_mapper_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the hot path -------------------------------------------------------------------------------
+    def new_history(self, n_rows):
+        return torch.full((n_rows, _capi.H_NTERMS), float("nan"), dtype=torch.float32, device=self.device)
+
+    def step(self, n_steps, lr, history=None, first_row=0):
+        hp = history.data_ptr() if history is not None else None
+        _capi.check(self._lib.tg_mapper_step(self._h, int(n_steps), float(lr), hp, int(first_row)))
+
+    def phase(self, phase, lr=0.0, history_row=None, gathered=None, nranks=0):
+        hp = history_row.data_ptr() if history_row is not None else None
+        gp = gathered.data_ptr() if gathered is not None else None
+        _capi.check(self._lib.tg_mapper_phase(self._h, int(phase), float(lr), hp, gp, int(nranks)))
+
+    def exchange_buffer(self, which):
+        """A float32 torch view (no copy) of one of the cross-GPU exchange vectors inside the workspace."""
+        p, n = ct.c_void_p(), ct.c_size_t()
+        _capi.check(self._lib.tg_mapper_exchange_buffer(self._h, int(which), ct.byref(p), ct.byref(n)))
+        off = p.value - self.workspace.data_ptr()
+        return self.workspace[off:off + 4 * n.value].view(torch.float32)
+
+    def result(self):
+        P = torch.empty((self.C, self.V), dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.tg_mapper_result(self._h, P.data_ptr(), None))
+        return P
+
+    def project(self):
+        Gh = torch.empty((self.V, self.K), dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.tg_mapper_project(self._h, Gh.data_ptr()))
+        return Gh
+
+    def logits(self):
+        """Views of M / Adam m / Adam v ([C, pitch] float32, columns >= V are padding)."""
+        pm, p1, p2 = ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
+        pitch, step = ct.c_int32(), ct.c_int64()
+        _capi.check(self._lib.tg_mapper_state(self._h, ct.byref(pm), ct.byref(p1), ct.byref(p2), ct.byref(pitch),
+                                              ct.byref(step)))
+        out = []
+        for p in (pm, p1, p2):
+            off = p.value - self.state.data_ptr()
+            out.append(self.state[off:off + 4 * self.C * pitch.value].view(torch.float32).view(self.C, pitch.value))
+        return out[0], out[1], out[2], int(step.value)
+
+    def set_step(self, step):
+        _capi.check(self._lib.tg_mapper_set_step(self._h, int(step)))
+
+    def profile_step(self, lr):
+        names = ct.create_string_buffer(4096)
+        ms = (ct.c_float * 64)()
+        n = ct.c_int()
+        _capi.check(self._lib.tg_mapper_profile_step(self._h, float(lr), names, 4096, ms, 64, ct.byref(n)))
+        ks = names.value.decode().split(";") if n.value else []
+        return list(zip(ks, [ms[i] for i in range(n.value)]))

@@ -1,0 +1,157 @@
+"""
+Host-side mirror of `tangram.mapping_optimizer` (reference: tangram/mapping_optimizer.py) on top of
+libtangram_hip.so.  Same class names, constructor arguments, `train()` signatures, return values and
+history keys as the reference, so that `tangram.mapping_utils.map_cells_to_space` (and
+`mapping_parameter_tuning.train_multiple_Mapper`) can use these classes unchanged:
+
+    Mapper(S, G, d=..., device=..., random_state=..., **hyperparameters).train(learning_rate=, num_epochs=, print_each=)
+        -> (mapping_matrix [C, V] float32 ndarray, training_history dict)       (mapping_utils.py:355-363)
+    MapperConstrained(...).train(...) -> (mapping_matrix, F_out, training_history)   (mapping_utils.py:383-389)
+
+All arithmetic of the training loop runs in hand-written HIP kernels (tangram_amd/csrc); this file
+only prepares inputs, owns the handle and formats the history.  There is no CPU path.
+
+Extra keyword (not in the reference): `gemm_precision` in {"bf16x3" (default, fp32-parity split-bf16
+matrix-core products), "fp32" (exact fp32 MFMA), "bf16"}.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+
+from . import _capi
+from .engine import HipMapperEngine
+
+_KEYS = ["total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg"]                       # reference :378
+_VAL_KEYS = ["val_total_loss", "val_gene_sim", "val_sp_sparsity_weighted_sim", "val_entropy"]  # reference :379
+_PRINT_NAMES = [  # reference :286-298, with the history column each comes from
+    ("Gene-voxel score", _capi.H_MAIN), ("Voxel-gene score", _capi.H_VG), ("Cell densities reg", _capi.H_KL),
+    ("Entropy reg", _capi.H_ENTROPY), ("L1 reg", _capi.H_L1), ("L2 reg", _capi.H_L2),
+    ("Spatial weighted score", _capi.H_NB), ("Cell type islands penalty", _capi.H_CT),
+]
+
+
+def _to_numpy_f32(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy().astype(np.float32)
+    if hasattr(x, "to_numpy"):            # pandas Series (density priors come from adata.obs)
+        x = x.to_numpy()
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def _print_terms(names_vals):
+    msg = ["{}: {:.3f}".format(k, v) for k, v in names_vals if not np.isnan(v)]
+    print(str(msg).replace("[", "").replace("]", "").replace("'", ""))        # reference :307
+
+
+class Mapper:
+    """MI355X-native drop-in for `tangram.mapping_optimizer.Mapper` (reference :14-408)."""
+
+    def __init__(
+        self,
+        S,
+        G,
+        train_genes_idx=None,
+        val_genes_idx=None,
+        d=None,
+        d_source=None,
+        lambda_g1=1.0,
+        lambda_d=0,
+        lambda_g2=0,
+        lambda_r=0,
+        lambda_l1=0,
+        lambda_l2=0,
+        lambda_neighborhood_g1=0,
+        voxel_weights=None,
+        lambda_getis_ord=0,
+        lambda_geary=0,
+        lambda_moran=0,
+        neighborhood_filter=None,
+        ct_encode=None,
+        lambda_ct_islands=0,
+        spatial_weights=None,
+        device="cuda:0",
+        adata_map=None,
+        random_state=None,
+        *,
+        gemm_precision="bf16x3",
+        M_init=None,
+    ):
+        if adata_map is not None:
+            raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :151-153)")
+        for name, lam in (("lambda_neighborhood_g1", lambda_neighborhood_g1), ("lambda_ct_islands", lambda_ct_islands),
+                          ("lambda_getis_ord", lambda_getis_ord), ("lambda_geary", lambda_geary),
+                          ("lambda_moran", lambda_moran)):
+            if lam and lam > 0:
+                raise NotImplementedError(f"{name} > 0: the spatial refinement terms are not built yet in tangram_amd")
+        self.device = torch.device(device)
+        self.random_state = random_state
+        S = _to_numpy_f32(S)
+        G = _to_numpy_f32(G)
+        if train_genes_idx is not None:                      # reference :87-92
+            S_train, G_train = S[:, train_genes_idx], G[:, train_genes_idx]
+        else:
+            S_train, G_train = S, G
+        self.val_genes_idx = val_genes_idx
+        self.lambda_d, self.lambda_g1, self.lambda_g2 = lambda_d, lambda_g1, lambda_g2
+        self.lambda_r, self.lambda_l1, self.lambda_l2 = lambda_r, lambda_l1, lambda_l2
+        self.target_density_enabled = d is not None          # reference :114
+        self.source_density_enabled = d_source is not None   # reference :118
+        d = _to_numpy_f32(d)
+        d_source = _to_numpy_f32(d_source)
+        # the reference ignores lambda_d when d is None (:212-221) and uses d_source only together with d (:214)
+        if M_init is None:
+            if self.random_state:                            # reference :148-150 (seed 0 / None => unseeded)
+                np.random.seed(seed=self.random_state)
+            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)
+        lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
+                       lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2)
+        self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
+                                       mode="mapper", device=self.device, precision=gemm_precision, lambdas=lambdas)
+
+    # ------------------------------------------------------------------------------------------------
+    def _history_dict(self, hist):
+        h = hist.detach().cpu().numpy()
+        out = {k: [] for k in _KEYS + _VAL_KEYS}
+        nan = float("nan")
+        for row in h:
+            out["total_loss"].append(np.array(row[_capi.H_TOTAL], dtype=np.float32))     # 0-d ndarray like :390
+            out["main_loss"].append(float(row[_capi.H_MAIN]))
+            out["vg_reg"].append(float(row[_capi.H_VG]) if self.lambda_g2 else nan)
+            out["kl_reg"].append(float(row[_capi.H_KL]) if self.target_density_enabled else nan)
+            out["entropy_reg"].append(float(row[_capi.H_ENTROPY]) if self.lambda_r else nan)
+        return out
+
+    def train(self, num_epochs, learning_rate=0.1, print_each=100, val_each=None):
+        """Run the optimizer; returns (mapping matrix ndarray [C, V], training_history) like the reference (:358-408)."""
+        if val_each is not None:
+            raise NotImplementedError("val_each (validation loss during training) is not built yet in tangram_amd")
+        if self.random_state:
+            torch.manual_seed(seed=self.random_state)        # reference :371-372 (no RNG is consumed afterwards)
+        if print_each:
+            logging.info(f"Printing scores every {print_each} epochs.")
+        eng = self._engine
+        hist = eng.new_history(max(int(num_epochs), 1))
+        t = 0
+        while t < num_epochs:
+            if print_each:
+                nxt = t if t % print_each == 0 else (t // print_each + 1) * print_each
+                n = min(nxt, num_epochs - 1) - t + 1
+            else:
+                n = num_epochs - t
+            eng.step(n, learning_rate, hist, t)
+            t += n
+            if print_each and (t - 1) % print_each == 0:
+                row = hist[t - 1].detach().cpu().numpy()
+                _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
+        output = eng.result().detach().cpu().numpy()         # reference :406-408
+        return output, self._history_dict(hist[:num_epochs])
+
+    # extras -----------------------------------------------------------------------------------------
+    def project_genes_device(self):
+        """softmax(M)^T S on the device (what mapping_utils.py:402 recomputes in NumPy)."""
+        return self._engine.project()

@@ -1,0 +1,63 @@
+"""Shared helpers of the parity tests (CPU-emulated and GPU).  The checker is the oracle / the golden
+fixtures generated from the unmodified reference; the thing under test is always the C-ABI library."""
+import os
+
+import numpy as np
+
+from oracle.gen_golden import CASES, build_inputs
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Stated fp32 tolerances (calibrated on the reference's own fp32-vs-fp64 / thread-count spread)
+TOL = {
+    #           per-epoch |d loss|   max|dP|   relFro(P^T S)
+    "fp32":   dict(loss=1e-5, P=2e-4, ghat=1e-4),
+    "bf16x3": dict(loss=1e-5, P=2e-4, ghat=1e-4),
+    "bf16":   dict(loss=1e-3, P=5e-2, ghat=1e-2),
+}
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def run_case(name, device, precision, epochs=None):
+    """Train the tangram_amd Mapper on golden case `name`; returns (P, history dict, Ghat, golden npz, epochs)."""
+    import tangram_amd.mapping_optimizer as mo
+    z = load_golden(name)
+    args, n_epochs, mode = build_inputs(name)
+    if epochs is not None:
+        n_epochs = min(n_epochs, epochs)
+    if mode == "constrained":
+        m = mo.MapperConstrained(device=device, gemm_precision=precision, M_init=z["f32_M0"], F_init=z["f32_F0"], **args)
+        P, F, hist = m.train(num_epochs=n_epochs, learning_rate=0.1, print_each=None)
+    else:
+        m = mo.Mapper(device=device, gemm_precision=precision, M_init=z["f32_M0"], **args)
+        P, hist = m.train(num_epochs=n_epochs, learning_rate=0.1, print_each=None)
+        F = None
+    Ghat = m.project_genes_device().detach().cpu().numpy()
+    return dict(P=P, F=F, hist=hist, Ghat=Ghat, z=z, epochs=n_epochs, mode=mode)
+
+
+def check_against_golden(res, precision, full_length):
+    """Compare with the reference's fp64 run (ground truth) within the stated fp32 tolerance."""
+    tol = TOL[precision]
+    z, n = res["z"], res["epochs"]
+    for k in ("main_loss", "total_loss", "kl_reg", "vg_reg", "entropy_reg"):
+        ref = z["f64_hist_" + k][:n]
+        got = np.array([float(x) for x in res["hist"][k]], dtype=np.float64)
+        if np.isnan(ref).all():
+            assert np.isnan(got).all(), f"{k}: expected NaN history like the reference"
+            continue
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(got - ref).max())
+        assert err <= tol["loss"] * scale, f"{k}: max per-epoch |delta| {err:.3e} > {tol['loss'] * scale:.1e}"
+    if full_length:
+        dP = float(np.abs(res["P"] - z["f64_P"]).max())
+        assert dP <= tol["P"], f"max|dP| {dP:.3e}"
+        rel = float(np.linalg.norm(res["Ghat"] - z["f64_Ghat"]) / np.linalg.norm(z["f64_Ghat"]))
+        assert rel <= tol["ghat"], f"relFro(P^T S) {rel:.3e}"
+        am = (res["P"].argmax(1) == z["f64_P"].argmax(1)).mean()
+        assert am >= (0.98 if precision != "bf16" else 0.9), f"argmax agreement {am:.3f}"
+    np.testing.assert_allclose(res["P"].sum(axis=1), 1.0, atol=1e-5)
+    assert (res["P"] >= 0).all()
