@@ -137,10 +137,13 @@ int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev);
 int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, float** m2_dev, int32_t* pitch, int64_t* step);
 int tg_mapper_set_step(tg_mapper* m, int64_t step);   /* after restoring state: recompute softmax statistics */
 
-/* Timing hooks for bench.py: HIP events recorded around each kernel of ONE step on the handle's stream.
- * names_out receives a ';'-separated list, ms_out the per-kernel milliseconds (n_max entries).       */
-int tg_mapper_profile_step(tg_mapper* m, float lr, char* names_out, size_t names_cap, float* ms_out, int n_max,
-                           int* n_out);
+/* Timing hooks for bench.py: while enabled, a HIP event is recorded on the handle's stream after every
+ * kernel launch of tg_mapper_step (no synchronisation).  tg_mapper_profile_read synchronises the stream once,
+ * aggregates the event intervals per kernel name (';'-separated list, total milliseconds, launch counts)
+ * and disables recording.                                                                              */
+int tg_mapper_profile(tg_mapper* m, int enable);
+int tg_mapper_profile_read(tg_mapper* m, char* names_out, size_t names_cap, float* total_ms_out, int* count_out,
+                           int n_max, int* n_out);
 
 #ifdef __cplusplus
 }

@@ -59,18 +59,19 @@ def _declare(lib):
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
     lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
-    lib.tg_mapper_profile_step.argtypes = [vp, f32, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_float), i32,
+    lib.tg_mapper_profile.argtypes = [vp, i32]
+    lib.tg_mapper_profile_read.argtypes = [vp, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_float), ct.POINTER(i32), i32,
                                            ct.POINTER(i32)]
     for name in ("tg_query_sizes", "tg_mapper_create", "tg_mapper_step", "tg_mapper_phase",
                  "tg_mapper_exchange_buffer", "tg_mapper_result", "tg_mapper_project", "tg_mapper_state",
-                 "tg_mapper_set_step", "tg_mapper_profile_step"):
+                 "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read"):
         getattr(lib, name).restype = i32
     return lib
 
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
            "tg_mapper_step", "tg_mapper_phase", "tg_mapper_exchange_buffer", "tg_mapper_result",
-           "tg_mapper_project", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile_step"]
+           "tg_mapper_project", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read"]
 
 
 def lib():

@@ -233,6 +233,7 @@ static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize,
     a.pair_out = want_pair ? m->fp(L.o_rowpair) : nullptr;
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
+    tg_prof_mark(m, "tg_merge_stats");
     TG_CK(tg_check_launch());
     return TG_OK;
 }
@@ -406,7 +407,6 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
     if ((rc = tg_launch_update<PR>(m, lr))) return rc;
     if ((rc = tg_merge(m, m->fp(m->L.o_part), m->L.nvt, true, false))) return rc;
-    tg_prof_mark(m, "tg_merge_stats");
     m->step += 1;
     TG_CK(tg_check_launch());
     return TG_OK;
@@ -530,37 +530,48 @@ extern "C" int tg_mapper_set_step(tg_mapper* m, int64_t step) {
     return rc;
 }
 
-extern "C" int tg_mapper_profile_step(tg_mapper* m, float lr, char* names_out, size_t names_cap, float* ms_out, int n_max,
-                                      int* n_out) {
+extern "C" int tg_mapper_profile(tg_mapper* m, int enable) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
-    m->prof = true;
-    m->prof_names.clear();
-#ifndef TG_SIM
-    m->prof_events.clear();
-#endif
-    tg_prof_mark(m, "start");
-    int rc = tg_dispatch_step(m, lr, nullptr);
-    m->prof = false;
-    if (rc) return rc;
-    int n = (int)m->prof_names.size() - 1;
-    std::string names;
-#ifndef TG_SIM
-    TG_CK(hipStreamSynchronize(m->stream));
-#endif
-    for (int i = 0; i < n; ++i) {
-        float ms = 0.f;
-#ifndef TG_SIM
-        hipEventElapsedTime(&ms, m->prof_events[i], m->prof_events[i + 1]);
-#endif
-        if (i < n_max && ms_out) ms_out[i] = ms;
-        if (i) names += ";";
-        names += m->prof_names[i + 1];
-    }
 #ifndef TG_SIM
     for (auto e : m->prof_events) hipEventDestroy(e);
     m->prof_events.clear();
 #endif
-    if (names_out && names_cap) { strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
-    if (n_out) *n_out = n;
+    m->prof_names.clear();
+    m->prof = enable != 0;
+    if (m->prof) tg_prof_mark(m, "start");
     return TG_OK;
+}
+
+extern "C" int tg_mapper_profile_read(tg_mapper* m, char* names_out, size_t names_cap, float* total_ms_out,
+                                      int* count_out, int n_max, int* n_out) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+#ifndef TG_SIM
+    TG_CK(hipStreamSynchronize(m->stream));
+#endif
+    std::vector<std::string> uniq;
+    std::vector<double> tot;
+    std::vector<int> cnt;
+    for (size_t i = 1; i < m->prof_names.size(); ++i) {
+        float ms = 0.f;
+#ifndef TG_SIM
+        hipEventElapsedTime(&ms, m->prof_events[i - 1], m->prof_events[i]);
+#endif
+        size_t j = 0;
+        for (; j < uniq.size(); ++j) if (uniq[j] == m->prof_names[i]) break;
+        if (j == uniq.size()) { uniq.push_back(m->prof_names[i]); tot.push_back(0.0); cnt.push_back(0); }
+        tot[j] += ms;
+        cnt[j] += 1;
+    }
+    std::string names;
+    for (size_t j = 0; j < uniq.size(); ++j) {
+        if (j) names += ";";
+        names += uniq[j];
+        if ((int)j < n_max) {
+            if (total_ms_out) total_ms_out[j] = (float)tot[j];
+            if (count_out) count_out[j] = cnt[j];
+        }
+    }
+    if (names_out && names_cap) { strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
+    if (n_out) *n_out = (int)uniq.size();
+    return tg_mapper_profile(m, 0);
 }

@@ -144,10 +144,15 @@ class HipMapperEngine:
     def set_step(self, step):
         _capi.check(self._lib.tg_mapper_set_step(self._h, int(step)))
 
-    def profile_step(self, lr):
+    def profile(self, enable=True):
+        _capi.check(self._lib.tg_mapper_profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """[(kernel name, total ms, launches)] since profile(True); synchronises the stream."""
         names = ct.create_string_buffer(4096)
         ms = (ct.c_float * 64)()
+        cnt = (ct.c_int * 64)()
         n = ct.c_int()
-        _capi.check(self._lib.tg_mapper_profile_step(self._h, float(lr), names, 4096, ms, 64, ct.byref(n)))
+        _capi.check(self._lib.tg_mapper_profile_read(self._h, names, 4096, ms, cnt, 64, ct.byref(n)))
         ks = names.value.decode().split(";") if n.value else []
-        return list(zip(ks, [ms[i] for i in range(n.value)]))
+        return [(k, float(ms[i]), int(cnt[i])) for i, k in enumerate(ks)]

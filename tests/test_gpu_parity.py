@@ -1,0 +1,118 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against
+ (i) fixtures generated from the unmodified reference (tests/golden, fp64 ground truth),
+ (ii) the oracle on seeded inputs at sizes it finishes in seconds,
+ (iii) size-independent properties at the BASELINE.json shape (30k x 1k x 10k)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import parity_common as pc
+from oracle.gen_golden import CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MAPPER_CASES = [n for n, c in CASES.items() if c[5] in ("cells", "clusters")]
+
+
+def test_native_library_is_the_one_running():
+    from tangram_amd import _capi
+    assert torch.cuda.is_available()
+    assert not _capi.is_emulated()
+    assert _capi.lib().tg_abi_version() == 1
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
+@pytest.mark.parametrize("name", MAPPER_CASES)
+def test_golden_reference_trajectories(name, precision):
+    res = pc.run_case(name, DEV, precision)
+    pc.check_against_golden(res, precision, full_length=True)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_medium_problem_against_oracle_fp64(precision):
+    """SURVEY 8c calibration size: 1500 x 120 x 400, 100 epochs, planted-assignment data."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.mapping_optimizer import Mapper
+    C, K, V = 1500, 120, 400
+    data = orc.make_synthetic(C, K, V, seed=0)
+    M0 = orc.reference_init_M(C, V, 42)
+    n = 100
+    m = Mapper(data["S"], data["G"], d=data["d"], lambda_d=1, lambda_g1=1, device=DEV, gemm_precision=precision, M_init=M0)
+    P, hist = m.train(num_epochs=n, learning_rate=0.1, print_each=None)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], lambda_d=1, M0=M0, dtype=np.float64)
+    Po, ho = o.train(n, 0.1)
+    for k in ("main_loss", "kl_reg", "total_loss"):
+        err = np.abs(np.array([float(x) for x in hist[k]]) - np.array(ho[k])).max()
+        assert err <= 1e-5, (k, err)
+    assert np.abs(P - Po).max() <= 2e-4
+    Gh = m.project_genes_device().cpu().numpy()
+    ref = Po.astype(np.float64).T @ data["S"].astype(np.float64)
+    assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= 1e-4
+    assert (P.argmax(1) == Po.argmax(1)).mean() > 0.99
+
+
+def test_single_step_gradient_fp32_path():
+    """One Adam step from zero moments moves every logit by -lr*sign(g) (|g| >> eps): compare the implied
+    gradient signs and, through a tiny-lr second run, magnitudes against the oracle's analytic gradient."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    C, K, V = 700, 90, 333
+    data = orc.make_synthetic(C, K, V, seed=4)
+    M0 = orc.reference_init_M(C, V, 9)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.7)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="fp32", lambdas=lam)
+    e.step(1, 0.1)
+    M1, m1, m2, st = e.logits()
+    g = (m1[:, :V] / 0.1).cpu().numpy()                  # exp_avg after one step = (1-beta1) * grad
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    _, dM = o.loss_and_grad()
+    rel = np.linalg.norm(g - dM) / np.linalg.norm(dM)
+    assert rel <= 1e-5, rel
+
+
+def test_forward_splits_and_determinism():
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    C, K, V = 2000, 200, 700
+    data = orc.make_synthetic(C, K, V, seed=8)
+    M0 = orc.reference_init_M(C, V, 3)
+    outs = []
+    for splits in (1, 4, 4):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3",
+                            lambdas=dict(lambda_d=1.0), fwd_splits=splits)
+        e.step(5, 0.1)
+        outs.append(e.result().cpu().numpy())
+    assert np.array_equal(outs[1], outs[2]), "same configuration must be bit-reproducible (no float atomics)"
+    assert np.abs(outs[0] - outs[1]).max() < 1e-6
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE.json shape, 1 GPU: size-independent invariants (the oracle cannot run this size)."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.synthetic import make_workload, init_logits
+    C, K, V = 30000, 1000, 10000
+    w = make_workload(C, K, V, DEV, seed=0)
+    M0 = init_logits(C, V, DEV, seed=42)
+    e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=DEV, precision="bf16x3", lambdas=dict(lambda_d=1.0))
+    del M0
+    n = 12
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    h = hist.cpu().numpy()
+    assert np.isfinite(h[:, :4][:, [0, 1, 3]]).all()
+    assert (np.diff(h[:, 1]) > 0).all(), "gene-voxel score must increase monotonically in the first epochs"
+    assert (np.diff(h[:, 3]) < 0).all(), "KL density term must decrease"
+    P = e.result()
+    rs = P.sum(dim=1)
+    assert float((rs - 1).abs().max()) < 1e-4 and float(P.min()) >= 0.0
+    # train-score invariant (reference tests/tangram_test.py:159-210): recompute the gene score from P after one more step
+    hist2 = e.new_history(1)
+    Gp = P.t() @ w["S"]
+    cos = torch.nn.functional.cosine_similarity(Gp, w["G"], dim=0).mean().item()
+    e.step(1, 0.1, hist2)
+    assert abs(cos - float(hist2[0, 1].item())) < 1e-4
+    # softmax statistics carried across iterations equal a from-scratch recomputation
+    M, m1, m2, step = e.logits()
+    P2 = torch.softmax(M[:, :V], dim=1)
+    assert float((e.result() - P2).abs().max()) < 1e-6
+    assert step == n + 1
