@@ -56,7 +56,7 @@ static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, NS, ESZ, BKE, prec, full;
     size_t o_Sk[2], o_St[2], o_dG[2], o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
-        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, total;
+        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, total;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
@@ -129,6 +129,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_rowq = take((size_t)TGP1_N * L->C * 4);
     L->o_rowpair = take((size_t)2 * L->C * 4);
     L->o_scal = take(64 * 4);
+    L->o_fsum = take(64 * 4);
     L->total = off;
     size_t so = 0;
     auto stake = [&](size_t bytes) { size_t o = so; so += rup(bytes, 256); return o; };
@@ -238,6 +239,25 @@ static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize,
     return TG_OK;
 }
 
+static int tg_launch_filter(tg_mapper* m, bool update, float lr, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgFilterArgs a;
+    float* F = (float*)(m->st + L.s_F);
+    a.F = F; a.mF = F + L.Cp; a.vF = F + 2 * (size_t)L.Cp;
+    a.fgate = m->fp(L.o_fgate); a.fsum = m->fp(L.o_fsum); a.rowq = m->fp(L.o_rowq);
+    a.d = m->fp(L.o_d); a.V = L.V; a.hist = hist_row ? hist_row : m->fp(L.o_scal);
+    a.C = L.C; a.do_update = update ? 1 : 0; a.has_density = m->cfg.has_density;
+    a.lambda_d = m->cfg.lambda_d; a.lambda_count = m->cfg.lambda_count; a.lambda_f_reg = m->cfg.lambda_f_reg;
+    a.target_count = m->cfg.target_count;
+    const double t = (double)(m->step + 1);
+    a.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
+    a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
+    TG_LAUNCH(tg_filter_kernel, 1, 1, 1024, 64, m->stream, a);
+    tg_prof_mark(m, "tg_filter_kernel");
+    return TG_OK;
+}
+
 extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void* state_dev, void* workspace_dev,
                                 void* hip_stream, tg_mapper** out) {
     TgLayout L;
@@ -247,7 +267,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     if (!in->S_dev || !in->G_dev || !in->M0_dev) return tg_fail(TG_ERR_INVALID, "S, G and M0 are required");
     if (cfg->has_density && !in->d_dev) return tg_fail(TG_ERR_INVALID, "has_density set but d is NULL");
     if (cfg->has_d_source && !in->d_source_dev) return tg_fail(TG_ERR_INVALID, "has_d_source set but d_source is NULL");
-    if (cfg->mode == TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_UNSUPPORTED, "constrained mode is not built yet");
+    if (cfg->mode == TG_MODE_CONSTRAINED && !in->F0_dev) return tg_fail(TG_ERR_INVALID, "constrained mode needs F0");
     tg_mapper* m = new (std::nothrow) tg_mapper();
     if (!m) return tg_fail(TG_ERR_INVALID, "out of host memory");
     m->cfg = *cfg; m->L = L;
@@ -280,6 +300,10 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
     if (tg_check_launch()) return bail(tg_fail(TG_ERR_HIP, "set-up kernel launch failed"));
+    if (cfg->mode == TG_MODE_CONSTRAINED) {
+        if (tg_memcpy(m->st + L.s_F, in->F0_dev, (size_t)L.C * 4, m->stream)) return bail(tg_fail(TG_ERR_HIP, "copy of F0 failed"));
+        if ((rc = tg_launch_filter(m, false, 0.f, nullptr))) return bail(rc);
+    }
     rc = tg_softmax_stats_from_scratch(m);
     if (!rc) rc = tg_merge(m, m->fp(L.o_rowpair), 1, /*finalize=*/true, /*want_pair=*/false);
     if (rc) return bail(rc);
@@ -331,6 +355,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     f.hist = hist_row ? hist_row : m->fp(L.o_scal);
     f.lambda_g1 = m->cfg.lambda_g1; f.lambda_g2 = m->cfg.lambda_g2; f.lambda_d = m->cfg.lambda_d;
     f.rho_scale = m->cfg.has_d_source ? 1.f : 1.f / (float)L.C;
+    f.fsum_dev = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fsum) : nullptr;
     f.K = L.K; f.Kp = L.Kp; f.V = L.V; f.Vr = L.Vr; f.V_total = L.Vtot; f.has_density = m->cfg.has_density;
     TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 64, m->stream, f);
     tg_prof_mark(m, "tg_loss_finalize");
@@ -350,7 +375,7 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     a.Sk[0] = m->ws + L.o_Sk[0]; a.Sk[1] = m->ws + L.o_Sk[1];
     a.M = (float*)(m->st + L.s_M); a.am = (float*)(m->st + L.s_m1); a.av = (float*)(m->st + L.s_m2);
     a.rshift = m->fp(L.o_rshift); a.rinvz = m->fp(L.o_rinvz);
-    a.fgate = nullptr;
+    a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     a.vcoef = m->fp(L.o_vcoef);
     a.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
     a.r = m->fp(L.o_rowq);
@@ -376,6 +401,7 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
         TgHistRegArgs h;
         h.rowq = m->fp(L.o_rowq); h.C = L.C; h.hist = hist_row ? hist_row : m->fp(L.o_scal);
         h.lambda_r = m->cfg.lambda_r; h.lambda_l1 = m->cfg.lambda_l1; h.lambda_l2 = m->cfg.lambda_l2;
+        h.constrained = (m->cfg.mode == TG_MODE_CONSTRAINED);
         TG_LAUNCH(tg_hist_regs, 1, 1, 1024, 64, m->stream, h);
         tg_prof_mark(m, "tg_hist_regs");
     }
@@ -406,6 +432,7 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
     if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
     if ((rc = tg_launch_update<PR>(m, lr))) return rc;
+    if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
     if ((rc = tg_merge(m, m->fp(m->L.o_part), m->L.nvt, true, false))) return rc;
     m->step += 1;
     TG_CK(tg_check_launch());
@@ -447,6 +474,7 @@ static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, con
             break;
         case 3:
             if ((rc = tg_launch_update<PR>(m, lr))) return rc;
+            if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
             rc = tg_merge(m, m->fp(L.o_part), L.nvt, false, true);
             m->step += 1;
             break;
@@ -487,10 +515,13 @@ extern "C" int tg_mapper_exchange_buffer(tg_mapper* m, int which, float** ptr_de
 extern "C" int tg_mapper_result(tg_mapper* m, float* P_out_dev, float* F_out_dev) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (!P_out_dev) return tg_fail(TG_ERR_INVALID, "P_out is NULL");
-    (void)F_out_dev;
     const TgLayout& L = m->L;
     TG_LAUNCH(tg_softmax_out, L.C, 1, 256, 0, m->stream, (const float*)(m->st + L.s_M),
               (const float*)m->fp(L.o_rshift), (const float*)m->fp(L.o_rinvz), L.C, L.V, L.Vp, P_out_dev);
+    if (F_out_dev) {
+        if (m->cfg.mode != TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_INVALID, "F_out requested from an unconstrained mapper");
+        TG_CK(tg_memcpy(F_out_dev, m->ws + L.o_fgate, (size_t)L.C * 4, m->stream));
+    }
     TG_CK(tg_check_launch());
     return TG_OK;
 }
@@ -525,7 +556,9 @@ extern "C" int tg_mapper_set_step(tg_mapper* m, int64_t step) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (step < 0) return tg_fail(TG_ERR_INVALID, "step < 0");
     m->step = step;
-    int rc = tg_softmax_stats_from_scratch(m);
+    int rc = TG_OK;
+    if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, false, 0.f, nullptr))) return rc;
+    rc = tg_softmax_stats_from_scratch(m);
     if (!rc) rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false);
     return rc;
 }

@@ -305,6 +305,7 @@ struct TgFinalizeArgs {
     float* hist;               // history row [TGH_NTERMS]
     float lambda_g1, lambda_g2, lambda_d;
     float rho_scale;           // 1/C for a uniform source, 1 for d_source (rho_v = colsum_v * rho_scale)
+    const float* fsum_dev;     // constrained mode: rho_v = colsum_v / sum_c f_c  (mapping_optimizer.py:512-513); else null
     int K, Kp, V, Vr, V_total, has_density;
 };
 
@@ -344,6 +345,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
     const float gv = tg_block_sum_1024(cs, red) / (float)a.K;
 
     float vs = 0.f, kl = 0.f;
+    const float rho_scale = a.fsum_dev ? 1.f / a.fsum_dev[0] : a.rho_scale;
     for (int v = t; v < a.Vr; v += 1024) {
         float va = 0.f, vb = 0.f, av = 0.f;
         if (v < a.V) {
@@ -360,9 +362,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
             if (a.has_density) {
                 const float colsum = a.Ghat[(size_t)v * a.Kp + a.K];
                 const float dv = a.d[v];
-                const float rho = colsum * a.rho_scale;
+                const float rho = colsum * rho_scale;
                 if (dv != 0.f) kl += dv * (tg_log(dv) - tg_log(rho));   // KLDivLoss(sum): xlogy(d,d) - d*log(rho)
-                av = -a.lambda_d * dv * a.rho_scale / rho;              // = -lambda_d d_v / colsum_v
+                av = -a.lambda_d * dv * rho_scale / rho;                // = -lambda_d d_v / colsum_v
             }
         }
         a.vcoef[v] = va;
@@ -632,7 +634,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
 }
 
 // entropy / L1 / L2 scalars (mapping_optimizer.py:224-231) from the per-row sums -> history row
-struct TgHistRegArgs { const float* rowq; int C; float* hist; float lambda_r, lambda_l1, lambda_l2; };
+struct TgHistRegArgs { const float* rowq; int C; float* hist; float lambda_r, lambda_l1, lambda_l2; int constrained; };
 
 // deterministic sum of a [n] vector into out[0] (single block)
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_vec_sum(const float* x, int n, float* out, float scale, int accumulate) {
@@ -658,11 +660,72 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs(TgHistRegArgs a) {
     l2 = tg_block_sum_1024(l2, red);
     if (threadIdx.x == 0) {
         float total = a.hist[TGH_TOTAL];
-        if (a.lambda_r != 0.f) { a.hist[TGH_ENTROPY] = -e; total += a.lambda_r * (-e); }
+        // Mapper reports -sum P log P (:224-225); MapperConstrained reports +sum P log P and subtracts it (:526,:575)
+        if (a.lambda_r != 0.f) { a.hist[TGH_ENTROPY] = a.constrained ? e : -e; total += a.lambda_r * (-e); }
         if (a.lambda_l1 != 0.f) { a.hist[TGH_L1] = l1; total += a.lambda_l1 * l1; }
         if (a.lambda_l2 != 0.f) { a.hist[TGH_L2] = l2; total += a.lambda_l2 * l2; }
         a.hist[TGH_TOTAL] = total;
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// MapperConstrained filter F (mapping_optimizer.py:490-493, :507, :528-532, :607): one block.
+//   init  : f = sigmoid(F), fsum = sum f
+//   update: df_c = Q_c + PA_c + lambda_d * dsum / fsum + lambda_count * sign(fsum - target) + lambda_f (1 - 2 f_c)
+//           dF = df f (1 - f); Adam(F); then f, fsum of the NEW F; count / f_reg scalars of the OLD f -> history
+// ----------------------------------------------------------------------------------------------
+struct TgFilterArgs {
+    float* F; float* mF; float* vF;      // [C] filter logits and Adam moments
+    float* fgate;                        // [C] sigmoid(F)
+    float* fsum;                         // [2]: fsum, scratch
+    const float* rowq;                   // [TGP1_N][C]
+    const float* d; int V;               // density prior (for sum d)
+    float* hist;
+    int C, do_update, has_density;
+    float lambda_d, lambda_count, lambda_f_reg, target_count;
+    float step_size, bc2_sqrt, beta1, beta2, eps;
+};
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel(TgFilterArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    const int t = threadIdx.x;
+    if (a.do_update) {
+        const float fsum = a.fsum[0];
+        float ds = 0.f;
+        if (a.has_density) for (int v = t; v < a.V; v += 1024) ds += a.d[v];
+        const float dsum = tg_block_sum_1024(ds, red);
+        float fr = 0.f;
+        for (int c = t; c < a.C; c += 1024) { const float f = a.fgate[c]; fr += f - f * f; }
+        const float freg = tg_block_sum_1024(fr, red);
+        const float cnt = fsum - a.target_count;
+        const float sgn = (cnt > 0.f) ? 1.f : ((cnt < 0.f) ? -1.f : 0.f);
+        for (int c = t; c < a.C; c += 1024) {
+            const float f = a.fgate[c];
+            float df = a.rowq[(size_t)TGP1_Q * a.C + c] + a.rowq[(size_t)TGP1_PA * a.C + c];
+            if (a.has_density) df += a.lambda_d * dsum / fsum;
+            df += a.lambda_count * sgn + a.lambda_f_reg * (1.f - 2.f * f);
+            const float g = df * f * (1.f - f);
+            const float e1 = a.mF[c] + (g - a.mF[c]) * (1.f - a.beta1);
+            const float e2 = a.vF[c] * a.beta2 + (1.f - a.beta2) * g * g;
+            const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
+            a.mF[c] = e1; a.vF[c] = e2;
+            a.F[c] = a.F[c] - a.step_size * (e1 / den);
+        }
+        if (t == 0) {
+            a.hist[TGH_COUNT] = fabsf(cnt);
+            a.hist[TGH_FREG] = freg;
+            a.hist[TGH_TOTAL] += a.lambda_count * fabsf(cnt) + a.lambda_f_reg * freg;
+        }
+    }
+    __syncthreads();
+    float fs = 0.f;
+    for (int c = t; c < a.C; c += 1024) {
+        const float f = 1.f / (1.f + tg_exp(-a.F[c]));
+        a.fgate[c] = f;
+        fs += f;
+    }
+    const float fsum_new = tg_block_sum_1024(fs, red);
+    if (t == 0) a.fsum[0] = fsum_new;
 }
 
 // merge (max, sum exp) partials over `nparts` -> rshift = max, rinvz = 1/Z ; optional raw output

@@ -119,10 +119,11 @@ class HipMapperEngine:
         off = p.value - self.workspace.data_ptr()
         return self.workspace[off:off + 4 * n.value].view(torch.float32)
 
-    def result(self):
+    def result(self, with_filter=False):
         P = torch.empty((self.C, self.V), dtype=torch.float32, device=self.device)
-        _capi.check(self._lib.tg_mapper_result(self._h, P.data_ptr(), None))
-        return P
+        F = torch.empty((self.C,), dtype=torch.float32, device=self.device) if with_filter else None
+        _capi.check(self._lib.tg_mapper_result(self._h, P.data_ptr(), F.data_ptr() if with_filter else None))
+        return (P, F) if with_filter else P
 
     def project(self):
         Gh = torch.empty((self.V, self.K), dtype=torch.float32, device=self.device)

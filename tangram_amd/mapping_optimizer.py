@@ -155,3 +155,88 @@ class Mapper:
     def project_genes_device(self):
         """softmax(M)^T S on the device (what mapping_utils.py:402 recomputes in NumPy)."""
         return self._engine.project()
+
+
+_KEYS_CONSTRAINED = ["total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg", "count_reg", "lambda_f_reg"]  # :609-617
+_PRINT_NAMES_CONSTRAINED = [("Score", _capi.H_MAIN), ("VG reg", _capi.H_VG), ("KL reg", _capi.H_KL),
+                            ("Entropy reg", _capi.H_ENTROPY), ("Count reg", _capi.H_COUNT),
+                            ("Lambda f reg", _capi.H_FREG)]                                              # :555-562
+
+
+class MapperConstrained:
+    """MI355X-native drop-in for `tangram.mapping_optimizer.MapperConstrained` (reference :411-639)."""
+
+    def __init__(
+        self,
+        S,
+        G,
+        d,
+        lambda_d=1,
+        lambda_g1=1,
+        lambda_g2=1,
+        lambda_r=0,
+        lambda_count=1,
+        lambda_f_reg=1,
+        target_count=None,
+        device="cuda:0",
+        adata_map=None,
+        random_state=None,
+        *,
+        gemm_precision="bf16x3",
+        M_init=None,
+        F_init=None,
+    ):
+        if adata_map is not None:
+            raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :476-478)")
+        self.device = torch.device(device)
+        self.random_state = random_state
+        S = _to_numpy_f32(S)
+        G = _to_numpy_f32(G)
+        self.target_density_enabled = d is not None
+        d = _to_numpy_f32(d)
+        self.lambda_d, self.lambda_g1, self.lambda_g2, self.lambda_r = lambda_d, lambda_g1, lambda_g2, lambda_r
+        self.lambda_count, self.lambda_f_reg = lambda_count, lambda_f_reg
+        self.target_count = G.shape[0] if target_count is None else target_count          # :480-483
+        if M_init is None or F_init is None:
+            if self.random_state:                                                          # :473-474
+                np.random.seed(seed=self.random_state)
+            np.random.normal(0, 1, (S.shape[0], G.shape[0]))                               # :475 (first draw is discarded by :485)
+            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)   # :485
+            F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)                 # :490
+        lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
+                       lambda_r=lambda_r, lambda_count=lambda_count, lambda_f_reg=lambda_f_reg)
+        self._engine = HipMapperEngine(S, G, M_init, d=d, F0=F_init, mode="constrained", device=self.device,
+                                       precision=gemm_precision, lambdas=lambdas, target_count=float(self.target_count))
+
+    def train(self, num_epochs, learning_rate=0.1, print_each=100):
+        """Returns (mapping matrix [C, V], filter [C], training_history) like the reference (:589-639).
+        History values are strings like the reference's (`str(x)`, :630); `total_loss` is `str(float)` rather than
+        the reference's tensor repr."""
+        if self.random_state:
+            torch.manual_seed(seed=self.random_state)
+        eng = self._engine
+        hist = eng.new_history(max(int(num_epochs), 1))
+        t = 0
+        while t < num_epochs:
+            if print_each:
+                nxt = t if t % print_each == 0 else (t // print_each + 1) * print_each
+                n = min(nxt, num_epochs - 1) - t + 1
+            else:
+                n = num_epochs - t
+            eng.step(n, learning_rate, hist, t)
+            t += n
+            if print_each and (t - 1) % print_each == 0:
+                row = hist[t - 1].detach().cpu().numpy()
+                _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES_CONSTRAINED])
+        P, F = eng.result(with_filter=True)
+        h = hist[:num_epochs].detach().cpu().numpy()
+        cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_COUNT, _capi.H_FREG]
+        active = [True, True, bool(self.lambda_g2), self.target_density_enabled, bool(self.lambda_r), True, True]
+        history = {k: [] for k in _KEYS_CONSTRAINED}
+        for row in h:
+            for k, c, on in zip(_KEYS_CONSTRAINED, cols, active):
+                history[k].append(str(float(row[c]) if on else float("nan")))
+        return P.detach().cpu().numpy(), F.detach().cpu().numpy(), history
+
+    def project_genes_device(self):
+        return self._engine.project()

@@ -26,6 +26,8 @@ def sim():
     ("clusters_dsource", "bf16x3", 6),   # d_source, 3 spot tiles, tiny C
     ("cells_allreg", "fp32", 8),         # entropy + L1 + L2 regularisers
     ("cells_ragged", "bf16", 6),
+    ("constrained", "fp32", 8),          # MapperConstrained: filter F, count / f_reg terms
+    ("constrained_entropy", "bf16x3", 6),
 ])
 def test_emulated_kernels_match_reference(sim, name, precision, epochs):
     res = pc.run_case(name, "cpu", precision, epochs=epochs)
