@@ -324,8 +324,8 @@ static int tg_launch_forward(tg_mapper* m) {
     a.St[0] = m->ws + L.o_St[0]; a.St[1] = m->ws + L.o_St[1];
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
-    a.nkt = L.nkt; a.nsteps = L.Cp / PR::BKE;
-    TG_LAUNCH((tg_fwd_kernel<PR>), L.nvt * L.nkt, L.nsplit, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    a.nkt = L.nkt; a.nvt = L.nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
+    TG_LAUNCH((tg_fwd_kernel<PR>), tg_fwd_grid(L.nvt, L.nkt, L.nsplit), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
     tg_prof_mark(m, "tg_fwd_kernel");
     return TG_OK;
 }
@@ -339,7 +339,7 @@ static int tg_launch_ghat_stats(tg_mapper* m) {
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
     TG_LAUNCH(tg_ghat_reduce, nrb, 1, 256, 4 * TG_RB * 2 * 4, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
-    TG_LAUNCH(tg_gene_reduce, (L.Kp + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
               m->fp(L.o_genestat));
     tg_prof_mark(m, "tg_gene_reduce");
     return TG_OK;
@@ -381,6 +381,10 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     a.r = m->fp(L.o_rowq);
     a.part = m->fp(L.o_part);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nct = L.nct;
+    // XCD bands along the longer tile axis when it is long enough to feed 8 XCDs, otherwise a plain linear order
+    if (L.nct >= 16 && L.nct >= L.nvt) { a.map = TgTileMap{1, L.nct, L.nvt}; a.map_major_is_cells = 1; }
+    else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, L.nct}; a.map_major_is_cells = 0; }
+    else { a.map = TgTileMap{0, L.nvt, L.nct}; a.map_major_is_cells = 0; }
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
     a.step_size = 0.f; a.bc2_sqrt = 1.f; a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
 }
@@ -390,8 +394,8 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
     TgBwdArgs a;
     tg_fill_bwd<PR>(m, a);
-    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 1, true>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
-    else TG_LAUNCH((tg_bwd_kernel<PR, 1, false>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 1, true>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    else TG_LAUNCH((tg_bwd_kernel<PR, 1, false>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
     tg_prof_mark(m, "tg_bwd_kernel<rowdot>");
     TgRowsumArgs r;
     r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
@@ -418,8 +422,8 @@ static int tg_launch_update(tg_mapper* m, float lr) {
     const double bc2 = 1.0 - pow((double)m->cfg.beta2, t);
     a.step_size = (float)((double)lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
-    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 2, true>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
-    else TG_LAUNCH((tg_bwd_kernel<PR, 2, false>), L.nvt * L.nct, 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 2, true>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    else TG_LAUNCH((tg_bwd_kernel<PR, 2, false>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
     tg_prof_mark(m, "tg_bwd_kernel<update>");
     return TG_OK;
 }
@@ -607,4 +611,15 @@ extern "C" int tg_mapper_profile_read(tg_mapper* m, char* names_out, size_t name
     if (names_out && names_cap) { strncpy(names_out, names.c_str(), names_cap - 1); names_out[names_cap - 1] = 0; }
     if (n_out) *n_out = (int)uniq.size();
     return tg_mapper_profile(m, 0);
+}
+
+// ---- test hooks (not part of the ABI): expose the workgroup -> tile maps so that their bijectivity can be checked on the host
+extern "C" int tg_debug_tilemap(int mode, int n_major, int n_minor, int b, int* major, int* minor) {
+    TgTileMap m{mode, n_major, n_minor};
+    if (b < 0) return tg_tilemap_grid(m);
+    return tg_tilemap(m, b, *major, *minor) ? 1 : 0;
+}
+extern "C" int tg_debug_fwd_map(int nvt, int nkt, int nsplit, int b, int* vt, int* kt, int* split) {
+    if (b < 0) return tg_fwd_grid(nvt, nkt, nsplit);
+    return tg_fwd_map(b, nvt, nkt, nsplit, *vt, *kt, *split) ? 1 : 0;
 }

@@ -17,6 +17,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define TG_KERNEL
 #define TG_DEV static inline
 #define TG_DEVM inline
+#define TG_HD static inline
 #define TG_LAUNCH_BOUNDS(n)
 #define threadIdx (hipsim::M().cur->tid)
 #define blockIdx (hipsim::M().blockIdx)
@@ -50,6 +51,7 @@ TG_DEV float tg_atomic_add(float* p, float v) { float o = *p; *p = o + v; return
 #define TG_KERNEL __global__
 #define TG_DEV __device__ __forceinline__
 #define TG_DEVM __device__ __forceinline__
+#define TG_HD __host__ __device__ static inline
 #define TG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 // all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned
 // (cdna_hip_programming.md Guideline 17; a second __shared__ object de-pipelines, section 5 trap 4a)

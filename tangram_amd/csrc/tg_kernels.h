@@ -71,6 +71,27 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
     }
 }
 
+// XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup b to XCD b % 8 (observed, used for speed
+// only: any mapping is correct).  Each XCD owns a contiguous band of the `major` tile axis and walks it in
+// 8 x 8 supertiles, so the ~64 workgroups resident on one XCD share 8 + 8 operand panels through that XCD's
+// private 4 MiB L2 instead of re-fetching them over the fabric.  Workgroups that fall off the grid exit.
+struct TgTileMap { int mode, n_major, n_minor; };     // mode 0: linear (major = b / n_minor)
+TG_HD int tg_tilemap_grid(const TgTileMap& m) {
+    if (m.mode == 0) return m.n_major * m.n_minor;
+    const int nb = (m.n_major + 7) / 8, nsM = (nb + 7) / 8, nsm = (m.n_minor + 7) / 8;
+    return 8 * nsM * nsm * 64;
+}
+TG_HD bool tg_tilemap(const TgTileMap& m, int b, int& major, int& minor) {
+    if (m.mode == 0) { major = b / m.n_minor; minor = b % m.n_minor; return true; }
+    const int nb = (m.n_major + 7) / 8, nsM = (nb + 7) / 8;
+    const int x = b & 7, j = b >> 3, s = j >> 6, w = j & 63;
+    const int sM = s % nsM, sm = s / nsM;
+    const int ml = sM * 8 + (w & 7);
+    major = x * nb + ml;
+    minor = sm * 8 + (w >> 3);
+    return ml < nb && major < m.n_major && minor < m.n_minor;
+}
+
 // a 128-row x 128-byte tile of an operand whose contraction axis is contiguous in memory
 template <class PR>
 struct TgKTile {
@@ -112,8 +133,20 @@ struct TgFwdArgs {
     float* Gpart;            // [nsplit][Vr][Kp]
     int C, V, Vp, Vr, Kp, Cp;
     int nkt;                 // gene tiles (Kp / 128)
+    int nvt, nsplit;         // spot tiles, cell-range splits
     int nsteps;              // Cp / BKE
 };
+// grid of the forward kernel: the nkt gene tiles that share one M panel (same spot tile, same cell range) sit
+// next to each other on ONE XCD; the 8 panels in flight on an XCD belong to the same cell range and share S^T.
+TG_HD int tg_fwd_grid(int nvt, int nkt, int nsplit) { return ((nvt * nsplit + 7) / 8) * 8 * nkt; }
+TG_HD bool tg_fwd_map(int b, int nvt, int nkt, int nsplit, int& vt, int& kt, int& split) {
+    const int bx = b & 7, bj = b >> 3;
+    const int unit = (bj / nkt) * 8 + bx;
+    kt = bj % nkt;
+    split = unit / nvt;
+    vt = unit % nvt;
+    return unit < nvt * nsplit;
+}
 
 template <class PR>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
@@ -121,9 +154,10 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int vt = blockIdx.x / a.nkt, kt = blockIdx.x % a.nkt;
+    int vt, kt, split;
+    if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, a.nsplit, vt, kt, split)) return;
+    const int nsplit = a.nsplit;
     const int v0 = vt * TG_TILE, k0 = kt * TG_TILE;
-    const int split = blockIdx.y, nsplit = gridDim.y;
     const int s_begin = (int)(((long long)a.nsteps * split) / nsplit);
     const int s_end = (int)(((long long)a.nsteps * (split + 1)) / nsplit);
 
@@ -271,17 +305,35 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) {
     }
 }
 
-// K2b: second stage of the per-gene sums (fixed order => deterministic)
+// K2b: second stage of the per-gene sums (fixed order => deterministic): 64 genes x 4 partial groups per block
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= Kp) return;
-    float d = 0.f, n = 0.f;
-    for (int b = 0; b < nrb; ++b) {
-        d += genepart[((size_t)b * 2 + 0) * Kp + k];
-        n += genepart[((size_t)b * 2 + 1) * Kp + k];
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;        // [4][64][2]
+    const int kx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kx;
+    float d0 = 0.f, n0 = 0.f, d1 = 0.f, n1 = 0.f;
+    if (k < Kp) {
+        int b = grp;
+        for (; b + 4 < nrb; b += 8) {
+            d0 += genepart[((size_t)b * 2 + 0) * Kp + k];
+            n0 += genepart[((size_t)b * 2 + 1) * Kp + k];
+            d1 += genepart[((size_t)(b + 4) * 2 + 0) * Kp + k];
+            n1 += genepart[((size_t)(b + 4) * 2 + 1) * Kp + k];
+        }
+        for (; b < nrb; b += 4) {
+            d0 += genepart[((size_t)b * 2 + 0) * Kp + k];
+            n0 += genepart[((size_t)b * 2 + 1) * Kp + k];
+        }
     }
-    genestat[k] = d;
-    genestat[Kp + k] = n;
+    red[(grp * 64 + kx) * 2 + 0] = d0 + d1;
+    red[(grp * 64 + kx) * 2 + 1] = n0 + n1;
+    __syncthreads();
+    if (grp == 0 && k < Kp) {
+        float d = 0.f, n = 0.f;
+        for (int g = 0; g < 4; ++g) { d += red[(g * 64 + kx) * 2 + 0]; n += red[(g * 64 + kx) * 2 + 1]; }
+        genestat[k] = d;
+        genestat[Kp + k] = n;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -440,6 +492,8 @@ struct TgBwdArgs {
     const float* r;                                // [C] (phase 2)
     float* part;                                   // phase 1: [nvt][NP1][C]; phase 2: [nvt][2][C]
     int C, V, Vp, Vr, Kp, nct;
+    TgTileMap map;                                 // major/minor = (cell tile, spot tile) or swapped, see map_major_is_cells
+    int map_major_is_cells;
     float lambda_r, lambda_l1, lambda_l2;
     float step_size, bc2_sqrt, beta1, beta2, eps;  // Adam (phase 2)
 };
@@ -451,7 +505,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_bwd_kernel(TgBwdArgs a) {
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int vt = blockIdx.x / a.nct, ct = blockIdx.x % a.nct;
+    int t_major, t_minor;
+    if (!tg_tilemap(a.map, blockIdx.x, t_major, t_minor)) return;
+    const int vt = a.map_major_is_cells ? t_minor : t_major, ct = a.map_major_is_cells ? t_major : t_minor;
     const int v0 = vt * TG_TILE, c0 = ct * TG_TILE;
     const int nsteps = a.Kp / PR::BKE;
 

@@ -53,3 +53,40 @@ def test_product_path_has_no_cpu_fallback():
     assert not _capi.is_emulated()
     with pytest.raises(RuntimeError):
         Mapper(np.ones((4, 3), np.float32), np.ones((5, 3), np.float32), device="cpu")
+
+
+@pytest.mark.parametrize("n_major,n_minor", [(235, 79), (79, 235), (16, 1), (17, 3), (64, 64), (1563, 391)])
+def test_xcd_tile_map_is_a_bijection(n_major, n_minor):
+    """Every tile of the backward grid is visited exactly once by the XCD-banded supertile order."""
+    from tangram_amd import _build
+    lib = ctypes.CDLL(_build.build())
+    mj, mn = ctypes.c_int(), ctypes.c_int()
+    for mode in (0, 1):
+        grid = lib.tg_debug_tilemap(mode, n_major, n_minor, -1, None, None)
+        seen = set()
+        for b in range(grid):
+            if lib.tg_debug_tilemap(mode, n_major, n_minor, b, ctypes.byref(mj), ctypes.byref(mn)):
+                assert 0 <= mj.value < n_major and 0 <= mn.value < n_minor
+                assert (mj.value, mn.value) not in seen
+                seen.add((mj.value, mn.value))
+        assert len(seen) == n_major * n_minor
+        if mode == 1:      # band property: a workgroup's XCD (b % 8) owns a contiguous band of the major axis
+            nb = (n_major + 7) // 8
+            for b in range(0, grid, 97):
+                if lib.tg_debug_tilemap(1, n_major, n_minor, b, ctypes.byref(mj), ctypes.byref(mn)):
+                    assert mj.value // nb == b % 8
+
+
+@pytest.mark.parametrize("nvt,nkt,nsplit", [(79, 8, 4), (1, 1, 1), (3, 2, 5), (10, 3, 1), (391, 16, 2)])
+def test_forward_grid_map_is_a_bijection(nvt, nkt, nsplit):
+    from tangram_amd import _build
+    lib = ctypes.CDLL(_build.build())
+    a, b_, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    grid = lib.tg_debug_fwd_map(nvt, nkt, nsplit, -1, None, None, None)
+    seen = set()
+    for b in range(grid):
+        if lib.tg_debug_fwd_map(nvt, nkt, nsplit, b, ctypes.byref(a), ctypes.byref(b_), ctypes.byref(c)):
+            key = (a.value, b_.value, c.value)
+            assert key not in seen and a.value < nvt and b_.value < nkt and c.value < nsplit
+            seen.add(key)
+    assert len(seen) == nvt * nkt * nsplit

@@ -11,7 +11,7 @@ from oracle.gen_golden import CASES
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-MAPPER_CASES = [n for n, c in CASES.items() if c[5] in ("cells", "clusters")]
+MAPPER_CASES = [n for n, c in CASES.items() if c[5] in ("cells", "clusters", "constrained")]
 
 
 def test_native_library_is_the_one_running():
@@ -49,6 +49,27 @@ def test_medium_problem_against_oracle_fp64(precision):
     ref = Po.astype(np.float64).T @ data["S"].astype(np.float64)
     assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= 1e-4
     assert (P.argmax(1) == Po.argmax(1)).mean() > 0.99
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_banded_tile_order_against_oracle_fp64(precision):
+    """A shape with >= 16 cell tiles and >= 16 spot tiles, so that the XCD-banded supertile order is active."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.mapping_optimizer import Mapper
+    C, K, V = 2500, 70, 2200
+    data = orc.make_synthetic(C, K, V, seed=12)
+    M0 = orc.reference_init_M(C, V, 11)
+    n = 25
+    lam = dict(lambda_d=1, lambda_g1=1, lambda_g2=0.5)
+    m = Mapper(data["S"], data["G"], d=data["d"], device=DEV, gemm_precision=precision, M_init=M0, **lam)
+    P, hist = m.train(num_epochs=n, learning_rate=0.1, print_each=None)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(n, 0.1)
+    tol = pc.TOL[precision]
+    for k in ("main_loss", "vg_reg", "kl_reg", "total_loss"):
+        err = np.abs(np.array([float(x) for x in hist[k]]) - np.array(ho[k])).max()
+        assert err <= tol["loss"], (k, err)
+    assert np.abs(P - Po).max() <= tol["P"]
 
 
 def test_single_step_gradient_fp32_path():
