@@ -1,0 +1,7 @@
+"""tangram_amd -- MI355X-native drop-in for the hot path of broadinstitute/Tangram:
+`map_cells_to_space` -> `Mapper` / `MapperConstrained` training loop, running in hand-written HIP kernels
+behind a C ABI (include/tangram_hip.h).  Importing this package does not import scanpy."""
+from .mapping_optimizer import Mapper, MapperConstrained          # noqa: F401
+from .mapping_utils import map_cells_to_space, adata_to_cluster_expression  # noqa: F401
+
+__version__ = "0.1.0"

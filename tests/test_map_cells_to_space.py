@@ -1,0 +1,111 @@
+"""`map_cells_to_space` drop-in surface (reference tangram/mapping_utils.py:141-428) with duck-typed AnnData,
+driven through the emulated C ABI on CPU.  Mirrors the reference's own tests (tests/tangram_test.py:67-152):
+argument errors, clusters / cells / constrained modes, result contract, train-score consistency."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests.hipsim.build_sim import build_sim
+from tangram_amd.anndata_lite import AnnDataLite
+from oracle import tangram_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from tangram_amd import _capi
+    path = build_sim()
+    if path is None:
+        pytest.skip("host clang not available to build the emulator")
+    _capi._install_library_for_tests(path)
+    yield path
+    _capi._install_library_for_tests(None)
+
+
+def _adatas(C=60, K=12, V=25, seed=2, extra_genes=3):
+    data = orc.make_synthetic(C, K + extra_genes, V, seed=seed)
+    genes = [f"g{i}" for i in range(K + extra_genes)]
+    rng = np.random.default_rng(seed)
+    obs_sc = pd.DataFrame({"subclass_label": rng.choice(["a", "b", "c"], size=C)}, index=[f"c{i}" for i in range(C)])
+    G = data["G"]
+    obs_sp = pd.DataFrame({"rna_count_based_density": G.sum(1) / G.sum(), "uniform_density": np.ones(V) / V},
+                          index=[f"s{i}" for i in range(V)])
+    ad_sc = AnnDataLite(data["S"], obs=obs_sc, var=pd.DataFrame(index=genes))
+    ad_sp = AnnDataLite(G, obs=obs_sp, var=pd.DataFrame(index=genes))
+    train = genes[:K]
+    for ad in (ad_sc, ad_sp):
+        ad.uns["training_genes"] = train
+        ad.uns["overlap_genes"] = genes
+    return ad_sc, ad_sp
+
+
+def test_invalid_arguments_raise_value_error(sim):
+    import tangram_amd as tg
+    ad_sc, ad_sp = _adatas()
+    with pytest.raises(ValueError, match="lambda_g1 cannot be 0"):
+        tg.map_cells_to_space(ad_sc, ad_sp, lambda_g1=0, device="cpu")
+    with pytest.raises(ValueError, match='Argument "mode"'):
+        tg.map_cells_to_space(ad_sc, ad_sp, mode="test", device="cpu")
+    with pytest.raises(ValueError, match="cluster_label must be specified"):
+        tg.map_cells_to_space(ad_sc, ad_sp, mode="clusters", device="cpu")
+    with pytest.raises(ValueError, match="density_prior"):
+        tg.map_cells_to_space(ad_sc, ad_sp, density_prior="bogus", device="cpu")
+    with pytest.raises(ValueError, match="target_count"):
+        tg.map_cells_to_space(ad_sc, ad_sp, mode="constrained", device="cpu")
+    ad_bad, _ = _adatas()
+    del ad_bad.uns["training_genes"]
+    with pytest.raises(ValueError, match="pp_adatas"):
+        tg.map_cells_to_space(ad_bad, ad_sp, device="cpu")
+
+
+def test_cells_mode_contract_and_train_score(sim):
+    import tangram_amd as tg
+    ad_sc, ad_sp = _adatas()
+    n = 6
+    ad_map = tg.map_cells_to_space(ad_sc, ad_sp, mode="cells", device="cpu", num_epochs=n, random_state=42,
+                                   verbose=False, gemm_precision="fp32")
+    assert ad_map.X.shape == (60, 25) and ad_map.X.dtype == np.float32
+    np.testing.assert_allclose(ad_map.X.sum(axis=1), 1.0, atol=1e-5)
+    assert list(ad_map.obs.index) == list(ad_sc.obs.index) and list(ad_map.var.index) == list(ad_sp.obs.index)
+    df = ad_map.uns["train_genes_df"]
+    assert list(df.columns) == ["train_score", "sparsity_sc", "sparsity_sp", "sparsity_diff"]
+    assert (np.diff(df["train_score"].to_numpy()) <= 1e-9).all()                    # sorted descending
+    hist = ad_map.uns["training_history"]
+    assert set(hist) >= {"total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg"} and len(hist["main_loss"]) == n
+    assert np.isnan(hist["vg_reg"]).all() and not np.isnan(hist["kl_reg"]).any()    # lambda_d forced to 1 (:214-215)
+    # same trajectory as the oracle with the reference's RNG for M (random_state=42)
+    train = ad_sc.uns["training_genes"]
+    S = ad_sc[:, train].X; G = ad_sp[:, train].X
+    o = orc.OracleMapper(S, G, d=ad_sp.obs["rna_count_based_density"].to_numpy(), lambda_d=1, random_state=42)
+    Po, ho = o.train(n)
+    np.testing.assert_allclose(hist["main_loss"], ho["main_loss"], atol=1e-5)
+    np.testing.assert_allclose(ad_map.X, Po, atol=1e-5)
+    # train-score consistency (reference tests/tangram_test.py:159-210)
+    o2 = orc.OracleMapper(S, G, d=ad_sp.obs["rna_count_based_density"].to_numpy(), lambda_d=1, M0=o.M)
+    terms, _ = o2.loss_and_grad()
+    assert abs(df["train_score"].mean() - terms["main_loss"]) < 1e-4
+
+
+def test_clusters_and_constrained_modes(sim):
+    import tangram_amd as tg
+    ad_sc, ad_sp = _adatas()
+    ad_map = tg.map_cells_to_space(ad_sc, ad_sp, mode="clusters", cluster_label="subclass_label", device="cpu",
+                                   num_epochs=4, random_state=42, verbose=False, gemm_precision="fp32")
+    assert ad_map.X.shape == (3, 25) and "cluster_density" in ad_map.obs.columns
+    # oracle on the aggregated matrix with d_source = cluster densities
+    vc = ad_sc.obs["subclass_label"].value_counts(normalize=True)
+    train = ad_sc.uns["training_genes"]
+    S = np.stack([ad_sc[:, train].X[(ad_sc.obs["subclass_label"] == l).to_numpy()].sum(0) for l in vc.index])
+    o = orc.OracleMapper(S, ad_sp[:, train].X, d=ad_sp.obs["rna_count_based_density"].to_numpy(),
+                         d_source=vc.to_numpy(), lambda_d=1, random_state=42)
+    Po, _ = o.train(4)
+    np.testing.assert_allclose(ad_map.X, Po, atol=1e-5)
+
+    ad_map2 = tg.map_cells_to_space(ad_sc, ad_sp, mode="constrained", target_count=10, device="cpu", num_epochs=4,
+                                    random_state=42, verbose=False, gemm_precision="fp32", lambda_g2=1)
+    assert "F_out" in ad_map2.obs.columns and ad_map2.X.shape == (60, 25)
+    assert all(isinstance(x, str) for x in ad_map2.uns["training_history"]["main_loss"])
+    oc = orc.OracleMapperConstrained(ad_sc[:, train].X, ad_sp[:, train].X, ad_sp.obs["rna_count_based_density"].to_numpy(),
+                                     lambda_d=1, lambda_g2=1, target_count=10, random_state=42)
+    Pc, Fc, _ = oc.train(4)
+    np.testing.assert_allclose(ad_map2.X, Pc, atol=1e-5)
+    np.testing.assert_allclose(ad_map2.obs["F_out"].to_numpy(), Fc, atol=1e-5)
