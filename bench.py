@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--shape", default=None, help="override C,K,V (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile edge (128 or 256); 0 = automatic")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +100,7 @@ def main():
     if world == 1:
         M0 = init_logits(C, V, device, seed=42)
         eng = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=args.precision, lambdas=lam,
-                              fwd_splits=args.splits)
+                              fwd_splits=args.splits, tile_size=args.tile)
         del M0
         run = lambda n: eng.step(n, lr)
         core = eng
@@ -107,7 +108,7 @@ def main():
         lo, hi = shard_bounds(V, world, rank)
         M0 = init_logits(C, hi - lo, device, seed=42 + rank)
         sh = ShardedMapperEngine(w["S"], w["G"][lo:hi].contiguous(), M0, w["d"][lo:hi].contiguous(), n_spots_total=V,
-                                 device=device, precision=args.precision, lambdas=lam, fwd_splits=args.splits)
+                                 device=device, precision=args.precision, lambdas=lam, fwd_splits=args.splits, tile_size=args.tile)
         del M0
         run = lambda n: sh.run(n, lr)
         core = sh.eng

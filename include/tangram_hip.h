@@ -14,7 +14,7 @@
  *   - the library allocates NO device memory: the caller provides `state` (logits + Adam moments)
  *     and `workspace` buffers whose sizes come from tg_query_sizes();
  *   - all work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises
- *     the stream except tg_mapper_read_history();
+ *     the stream except tg_mapper_profile_read();
  *   - return value 0 = success, negative = tg_status; tg_last_error() gives the message of the last
  *     failure on the calling thread.  The library never aborts.
  *   - a handle is not thread-safe; different handles may be used from different threads.
@@ -62,6 +62,7 @@ typedef struct tg_config {
     int32_t has_density;     /* d given (target_density_enabled, :114) */
     int32_t has_d_source;    /* d_source given (:118) */
     int32_t fwd_splits;      /* 0 = choose automatically; >0 = number of cell-range splits of the forward GEMM */
+    int32_t tile_size;       /* 0 = choose automatically; 128 or 256 = GEMM output tile edge (tuning / tests)        */
     float lambda_g1, lambda_d, lambda_g2, lambda_r, lambda_l1, lambda_l2;
     float lambda_count, lambda_f_reg, target_count;     /* constrained mode (:426-428, :480-483) */
     float beta1, beta2, eps;                            /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 (:373) */

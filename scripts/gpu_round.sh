@@ -12,8 +12,11 @@ if [ -z "$2" ]; then
   echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
   tail -15 $O/pytest_gpu.log
 fi
+for P in bf16x3 bf16 fp32; do
+  echo "== bench $P"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
+done
 for P in bf16x3 bf16; do
-  echo "== bench $P"; timeout 900 python bench.py --steps 30 --warmup 5 --precision $P --no-cpu-baseline > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
+  echo "== bench $P tile128"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --tile 128 --no-cpu-baseline > $O/bench_${P}_t128.json 2> $O/bench_${P}_t128.err; echo "rc=$?"
 done
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp

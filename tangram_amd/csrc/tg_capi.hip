@@ -54,8 +54,8 @@ extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 struct TgLayout {
-    int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, NS, ESZ, BKE, prec, full;
-    size_t o_Sk[2], o_St[2], o_dG[2], o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
+    int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
+    size_t o_Sk, o_St, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
         o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, total;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
@@ -84,30 +84,28 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->C = cfg->n_cells; L->K = cfg->n_genes; L->V = cfg->n_spots;
     L->Vtot = cfg->n_spots_total > 0 ? cfg->n_spots_total : cfg->n_spots;
     L->prec = cfg->precision;
-    L->NS = cfg->precision == TG_PREC_BF16X3 ? 2 : 1;
-    L->ESZ = cfg->precision == TG_PREC_F32 ? 4 : 2;
-    L->BKE = cfg->precision == TG_PREC_F32 ? 32 : 64;
-    L->Kp = (int)rup((size_t)L->K + 1, 128);
+    L->ESZ = cfg->precision == TG_PREC_BF16 ? 2 : 4;      // operand bytes per contraction element (bf16x3: hi + lo)
+    L->BKE = cfg->precision == TG_PREC_BF16 ? 64 : 32;     // contraction elements per 128-byte step
+    if (cfg->tile_size != 0 && cfg->tile_size != 128 && cfg->tile_size != 256) return tg_fail(TG_ERR_INVALID, "tile_size must be 0, 128 or 256");
+    // large geometry (256 x 256 tiles, one 512-thread workgroup per CU) once every tile axis is long enough to fill the chip
+    L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 1024) ? 256 : 128);
+    L->Kp = (int)rup((size_t)L->K + 1, L->T);
     L->Vp = (int)rup(L->V, 64);
-    L->Vr = (int)rup(L->V, 128);
+    L->Vr = (int)rup(L->V, L->T);
     L->Cp = (int)rup(L->C, 64);
-    L->Cr = (int)rup(L->C, 128);
-    L->nvt = L->Vr / 128; L->nct = L->Cr / 128; L->nkt = L->Kp / 128;
+    L->Cr = (int)rup(L->C, L->T);
+    L->nvt = L->Vr / L->T; L->nct = L->Cr / L->T; L->nkt = L->Kp / L->T;
     L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
-    const int slots = 256 * (L->NS == 2 ? 1 : 2);
+    const int slots = 256 * (L->T == 256 ? 1 : 2);
     L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots);
     if (L->nsplit > nsteps) L->nsplit = nsteps;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
-    for (int p = 0; p < 2; ++p) {
-        L->o_Sk[p] = take((size_t)L->Cr * L->Kp * L->ESZ);
-        L->o_St[p] = take((size_t)L->Kp * L->Cp * L->ESZ);
-        L->o_dG[p] = take((size_t)L->Vr * L->Kp * L->ESZ);
-        if (L->NS == 1) { break; }
-    }
-    if (L->NS == 1) { L->o_Sk[1] = L->o_Sk[0]; L->o_St[1] = L->o_St[0]; L->o_dG[1] = L->o_dG[0]; }
+    L->o_Sk = take((size_t)L->Cr * L->Kp * L->ESZ);
+    L->o_St = take((size_t)L->Kp * L->Cp * L->ESZ);
+    L->o_dG = take((size_t)L->Vr * L->Kp * L->ESZ);
     L->o_Gp = take((size_t)L->Vr * L->Kp * 4);
     L->o_Ghat = take((size_t)L->Vr * L->Kp * 4);
     L->o_Gpart = take((size_t)L->nsplit * L->Vr * L->Kp * 4);
@@ -187,15 +185,15 @@ static void tg_prof_mark(tg_mapper* m, const char* name) {
     m->prof_names.push_back(name);
 }
 
-template <class PR>
+template <class PR, class GE>
 static int tg_lds_attr() {
 #ifndef TG_SIM
-    const int bytes = 2 * TgStage<PR>::kBytes;
-    TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    const int bytes = GE::LDS_BYTES;
+    TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 #endif
     return TG_OK;
 }
@@ -207,13 +205,13 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     TgPrepSArgs a;
     a.S = in->S_dev; a.C = L.C; a.K = L.K;
     a.aug = m->cfg.has_d_source ? in->d_source_dev : nullptr;
-    a.Sk[0] = m->ws + L.o_Sk[0]; a.Sk[1] = m->ws + L.o_Sk[1]; a.Cr = L.Cr; a.Kp = L.Kp;
-    a.St[0] = m->ws + L.o_St[0]; a.St[1] = m->ws + L.o_St[1]; a.Cp = L.Cp;
+    a.Sk = m->ws + L.o_Sk; a.Cr = L.Cr; a.Kp = L.Kp;
+    a.St = m->ws + L.o_St; a.Cp = L.Cp;
     const size_t n1 = (size_t)L.Cr * (L.Kp / PR::CH), n2 = (size_t)L.Kp * (L.Cp / PR::CH);
     TG_LAUNCH((tg_prep_sk<PR>), (n1 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_CK(tg_check_launch());
-    return tg_lds_attr<PR>();
+    return L.T == 256 ? tg_lds_attr<PR, TgGeoLarge>() : tg_lds_attr<PR, TgGeoSmall>();
 }
 
 static int tg_softmax_stats_from_scratch(tg_mapper* m) {
@@ -321,11 +319,13 @@ static int tg_launch_forward(tg_mapper* m) {
     TgFwdArgs a;
     a.M = (const float*)(m->st + L.s_M);
     a.rshift = m->fp(L.o_rshift); a.rscale = m->fp(L.o_rscale);
-    a.St[0] = m->ws + L.o_St[0]; a.St[1] = m->ws + L.o_St[1];
+    a.St = m->ws + L.o_St;
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
     a.nkt = L.nkt; a.nvt = L.nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
-    TG_LAUNCH((tg_fwd_kernel<PR>), tg_fwd_grid(L.nvt, L.nkt, L.nsplit), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    const int grid = tg_fwd_grid(L.nvt, L.nkt, L.nsplit);
+    if (L.T == 256) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoLarge>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
+    else TG_LAUNCH((tg_fwd_kernel<PR, TgGeoSmall>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
     tg_prof_mark(m, "tg_fwd_kernel");
     return TG_OK;
 }
@@ -361,7 +361,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     tg_prof_mark(m, "tg_loss_finalize");
     TgEmitArgs e;
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
-    e.dG[0] = m->ws + L.o_dG[0]; e.dG[1] = m->ws + L.o_dG[1];
+    e.dG = m->ws + L.o_dG;
     e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K;
     TG_LAUNCH((tg_dghat_emit<PR>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
     tg_prof_mark(m, "tg_dghat_emit");
@@ -371,8 +371,8 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
 template <class PR>
 static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     const TgLayout& L = m->L;
-    a.dG[0] = m->ws + L.o_dG[0]; a.dG[1] = m->ws + L.o_dG[1];
-    a.Sk[0] = m->ws + L.o_Sk[0]; a.Sk[1] = m->ws + L.o_Sk[1];
+    a.dG = m->ws + L.o_dG;
+    a.Sk = m->ws + L.o_Sk;
     a.M = (float*)(m->st + L.s_M); a.am = (float*)(m->st + L.s_m1); a.av = (float*)(m->st + L.s_m2);
     a.rshift = m->fp(L.o_rshift); a.rinvz = m->fp(L.o_rinvz);
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
@@ -380,7 +380,7 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     a.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
     a.r = m->fp(L.o_rowq);
     a.part = m->fp(L.o_part);
-    a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nct = L.nct;
+    a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nsteps = L.Kp / PR::BKE;
     // XCD bands along the longer tile axis when it is long enough to feed 8 XCDs, otherwise a plain linear order
     if (L.nct >= 16 && L.nct >= L.nvt) { a.map = TgTileMap{1, L.nct, L.nvt}; a.map_major_is_cells = 1; }
     else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, L.nct}; a.map_major_is_cells = 0; }
@@ -389,13 +389,25 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     a.step_size = 0.f; a.bc2_sqrt = 1.f; a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
 }
 
+template <class PR, int PHASE>
+static void tg_launch_bwd(tg_mapper* m, const TgBwdArgs& a) {
+    const TgLayout& L = m->L;
+    const int grid = tg_tilemap_grid(a.map);
+    if (L.T == 256) {
+        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, PHASE, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, PHASE, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
+    } else {
+        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, PHASE, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, PHASE, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
+    }
+}
+
 template <class PR>
 static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
     TgBwdArgs a;
     tg_fill_bwd<PR>(m, a);
-    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 1, true>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
-    else TG_LAUNCH((tg_bwd_kernel<PR, 1, false>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    tg_launch_bwd<PR, 1>(m, a);
     tg_prof_mark(m, "tg_bwd_kernel<rowdot>");
     TgRowsumArgs r;
     r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
@@ -422,8 +434,7 @@ static int tg_launch_update(tg_mapper* m, float lr) {
     const double bc2 = 1.0 - pow((double)m->cfg.beta2, t);
     a.step_size = (float)((double)lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
-    if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, 2, true>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
-    else TG_LAUNCH((tg_bwd_kernel<PR, 2, false>), tg_tilemap_grid(a.map), 1, 256, 2 * TgStage<PR>::kBytes, m->stream, a);
+    tg_launch_bwd<PR, 2>(m, a);
     tg_prof_mark(m, "tg_bwd_kernel<update>");
     return TG_OK;
 }

@@ -19,6 +19,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define TG_DEVM inline
 #define TG_HD static inline
 #define TG_LAUNCH_BOUNDS(n)
+#define TG_LAUNCH_BOUNDS2(n, w)
 #define threadIdx (hipsim::M().cur->tid)
 #define blockIdx (hipsim::M().blockIdx)
 #define blockDim (hipsim::M().blockDim)
@@ -53,6 +54,7 @@ TG_DEV float tg_atomic_add(float* p, float v) { float o = *p; *p = o + v; return
 #define TG_DEVM __device__ __forceinline__
 #define TG_HD __host__ __device__ static inline
 #define TG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define TG_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
 // all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned
 // (cdna_hip_programming.md Guideline 17; a second __shared__ object de-pipelines, section 5 trap 4a)
 #define TG_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char tg_lds[]
@@ -84,16 +86,20 @@ TG_DEV float tg_bf16_hi_to_f32(unsigned packed) { return __builtin_bit_cast(floa
 TG_DEV float tg_fmax(float a, float b) { return a > b ? a : b; }
 
 // ----------------------------------------------------------------------------------------------
-// GEMM operand precision policies.  Every operand tile row in LDS is 128 bytes = 8 chunks of
-// 16 bytes; a chunk is the unit a lane feeds to the matrix core (8 bf16 or 4 f32 along the
-// contraction axis).  Lane (row = l&15, g = l>>4) reads chunk 4q+g, q = 0,1; the contraction
-// index order inside a tile row is irrelevant as long as A and B agree, which they do.
-//   PrecF32   : exact f32 MFMA (v_mfma_f32_16x16x4_f32), 4 per chunk pair.      32 elements / row
-//   PrecBF16  : operands rounded to bf16, f32 accumulate.                        64 elements / row
-//   PrecBF16x3: operands split hi+lo bf16, a*b ~ ah*bh + ah*bl + al*bh, f32 acc  64 elements / row
+// GEMM operand precision policies.
+//
+// Operand format (both in HBM and in LDS): an operand row is a sequence of contraction STEPS of 128 bytes
+// = 8 chunks of 16 bytes; a chunk is what one lane feeds to the matrix core (8 bf16 or 4 f32 along the
+// contraction axis).  Lane (row = l&15, g = l>>4) reads chunk 4*(q+p)+g; the order of the contraction
+// index inside a step is irrelevant as long as A and B agree, which they do.
+//   PrecF32   : exact f32 MFMA (v_mfma_f32_16x16x4_f32).  step = 32 elements, chunks 0..7 = 8 k-chunks
+//   PrecBF16  : operands rounded to bf16, f32 accumulate.  step = 64 elements, chunks 0..7 = 8 k-chunks
+//   PrecBF16x3: split bf16: x = hi + lo, a*b ~ ah*bh + ah*bl + al*bh (f32 accumulate) -- fp32-parity.
+//               step = 32 elements: chunks 0..3 = hi of the 4 k-chunks, chunks 4..7 = their lo parts.
+//   KQ = k-chunk groups per step a lane walks through, NP = parts (hi, lo) per fragment.
 // ----------------------------------------------------------------------------------------------
 struct PrecF32 {
-    static constexpr int kId = 0, NS = 1, CH = 4, BKE = 32, ESZ = 4;
+    static constexpr int kId = 0, KQ = 2, NP = 1, CH = 4, BKE = 32, ESZ = 4, KCH = 8;
     TG_DEVM static void cvt(const float (&x)[4], u32x4& hi, u32x4& lo) {
         hi = u32x4{__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
                    __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
@@ -110,7 +116,7 @@ struct PrecF32 {
 };
 
 struct PrecBF16 {
-    static constexpr int kId = 1, NS = 1, CH = 8, BKE = 64, ESZ = 2;
+    static constexpr int kId = 1, KQ = 2, NP = 1, CH = 8, BKE = 64, ESZ = 2, KCH = 8;
     TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
         hi = u32x4{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3]), tg_pack_bf16(x[4], x[5]), tg_pack_bf16(x[6], x[7])};
         lo = hi;
@@ -119,7 +125,7 @@ struct PrecBF16 {
 };
 
 struct PrecBF16x3 {
-    static constexpr int kId = 2, NS = 2, CH = 8, BKE = 64, ESZ = 2;
+    static constexpr int kId = 2, KQ = 1, NP = 2, CH = 8, BKE = 32, ESZ = 4, KCH = 4;   // ESZ: bytes per element incl. lo
     TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
         float r[8];
 #pragma unroll
@@ -138,6 +144,16 @@ struct PrecBF16x3 {
         return c;
     }
 };
+
+// Write the operand image of CH consecutive contraction elements (k-chunk `kc` of step `step`) of one operand row.
+template <class PR>
+TG_DEV void tg_store_operand_chunk(unsigned char* row_base, int step, int kc, const float (&x)[PR::CH]) {
+    u32x4 hi, lo;
+    PR::cvt(x, hi, lo);
+    u32x4* dst = (u32x4*)(row_base + (size_t)step * 128);
+    dst[kc] = hi;
+    if (PR::NP == 2) dst[4 + kc] = lo;
+}
 
 // XOR swizzle of the 16-byte chunk index inside a 128-byte LDS tile row: ds_read_b128 of 16
 // consecutive rows at one logical chunk touches all 16 slots of the two 256-byte bank rows.

@@ -34,46 +34,80 @@ enum { TGH_TOTAL = 0, TGH_MAIN, TGH_VG, TGH_KL, TGH_ENTROPY, TGH_L1, TGH_L2, TGH
        TGH_NTERMS = 16 };
 
 // ----------------------------------------------------------------------------------------------
-// shared GEMM tile machinery: 128 x 128 output tile, 256 threads = 4 waves as 2 x 2, each wave
-// 64 x 64 = 4 x 4 MFMA 16x16 fragments.  One LDS stage = NS x {A tile, B tile}, each tile
-// 128 rows x 8 chunks (16 B) with the XOR swizzle of tg_swz.
+// shared GEMM tile machinery.  Output tile TM x TN, 64*WM*WN threads, each wave owns (TM/WM) x (TN/WN)
+// = FM x FN MFMA 16x16 fragments.  One LDS stage = {A tile: TM rows, B tile: TN rows} of 128-byte rows
+// (8 chunks of 16 B, XOR-swizzled by tg_swz); two stages are double-buffered.
+//   small geometry: 128 x 128, 256 threads (2 x 2 waves of 64 x 64)   -- small problems, 2 workgroups / CU
+//   large geometry: 256 x 256, 512 threads (2 x 4 waves of 128 x 64)  -- half the staged bytes per flop
+// (profiles/r01: the 128^2 kernels are bound by the global->LDS staging rate, ~17 B/clk/CU, not by MFMA)
 // ----------------------------------------------------------------------------------------------
-#define TG_TILE 128
-#define TG_TILE_CHUNKS (TG_TILE * 8)
-
-template <class PR>
-struct TgStage {
-    static constexpr int kChunks = PR::NS * 2 * TG_TILE_CHUNKS;     // u32x4 units
-    static constexpr int kBytes = kChunks * 16;
+template <int TM_, int TN_, int WM_, int WN_>
+struct TgGeo {
+    static constexpr int TM = TM_, TN = TN_, WM = WM_, WN = WN_;
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int FM = TM / (16 * WM), FN = TN / (16 * WN);
+    static constexpr int A_CHUNKS = TM * 8, B_CHUNKS = TN * 8, STAGE_CHUNKS = A_CHUNKS + B_CHUNKS;
+    static constexpr int STAGE_BYTES = STAGE_CHUNKS * 16, LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int LA = A_CHUNKS / NT, LB = B_CHUNKS / NT;       // 16-byte loads per thread per stage
+    static_assert(NT == 2 * TM, "forward A staging assumes (TM/4 spot quads) x 8 chunk slots == NT threads");
+    static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0 && FM % 4 == 0, "tile / thread mismatch");
 };
+typedef TgGeo<128, 128, 2, 2> TgGeoSmall;
+typedef TgGeo<256, 256, 2, 4> TgGeoLarge;
 
-template <class PR>
-TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+template <class PR, class GE>
+TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[GE::FM][GE::FN]) {
     const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int ch = 4 * q + g;
-        u32x4 a[4][PR::NS], b[4][PR::NS];
+    for (int q = 0; q < PR::KQ; ++q) {
+        u32x4 b[GE::FN][PR::NP];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const int ra = wm * 64 + f * 16 + r;
-            const int rb = wn * 64 + f * 16 + r;
+        for (int f = 0; f < GE::FN; ++f) {
+            const int rb = wn * (GE::TN / GE::WN) + f * 16 + r;
 #pragma unroll
-            for (int p = 0; p < PR::NS; ++p) {
-                a[f][p] = st[(p * 2 + 0) * TG_TILE_CHUNKS + ra * 8 + tg_swz(ra, ch)];
-                b[f][p] = st[(p * 2 + 1) * TG_TILE_CHUNKS + rb * 8 + tg_swz(rb, ch)];
-            }
+            for (int p = 0; p < PR::NP; ++p) b[f][p] = st[GE::A_CHUNKS + rb * 8 + tg_swz(rb, 4 * (q + p) + g)];
         }
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
+        for (int fb = 0; fb < GE::FM; fb += 4) {
+            u32x4 a[4][PR::NP];
 #pragma unroll
-            for (int fj = 0; fj < 4; ++fj) acc[fi][fj] = PR::mma(a[fi], b[fj], acc[fi][fj]);
+            for (int f = 0; f < 4; ++f) {
+                const int ra = wm * (GE::TM / GE::WM) + (fb + f) * 16 + r;
+#pragma unroll
+                for (int p = 0; p < PR::NP; ++p) a[f][p] = st[ra * 8 + tg_swz(ra, 4 * (q + p) + g)];
+            }
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < GE::FN; ++fj) acc[fb + fi][fj] = PR::mma(a[fi], b[fj], acc[fb + fi][fj]);
+        }
     }
 }
 
+// ROWS x 128-byte slab (one contraction step) of an operand stored as [row][step][128 B]
+template <int ROWS, int NT>
+struct TgKTile {
+    static constexpr int L = ROWS * 8 / NT;
+    u32x4 v[L];
+    TG_DEVM void load(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, int t) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int idx = t + i * NT;
+            v[i] = *(const u32x4*)(base + (row0 + (idx >> 3)) * pitch_bytes + step * 128 + (idx & 7) * 16);
+        }
+    }
+    TG_DEVM void store(u32x4* tile, int t) const {
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const int idx = t + i * NT, row = idx >> 3;
+            tile[row * 8 + tg_swz(row, idx & 7)] = v[i];
+        }
+    }
+};
+
 // XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup b to XCD b % 8 (observed, used for speed
 // only: any mapping is correct).  Each XCD owns a contiguous band of the `major` tile axis and walks it in
-// 8 x 8 supertiles, so the ~64 workgroups resident on one XCD share 8 + 8 operand panels through that XCD's
+// 8 x 8 supertiles, so the workgroups resident on one XCD share 8 + 8 operand panels through that XCD's
 // private 4 MiB L2 instead of re-fetching them over the fabric.  Workgroups that fall off the grid exit.
 struct TgTileMap { int mode, n_major, n_minor; };     // mode 0: linear (major = b / n_minor)
 TG_HD int tg_tilemap_grid(const TgTileMap& m) {
@@ -92,35 +126,9 @@ TG_HD bool tg_tilemap(const TgTileMap& m, int b, int& major, int& minor) {
     return ml < nb && major < m.n_major && minor < m.n_minor;
 }
 
-// a 128-row x 128-byte tile of an operand whose contraction axis is contiguous in memory
-template <class PR>
-struct TgKTile {
-    u32x4 v[PR::NS][4];
-    TG_DEVM void load(const unsigned char* const (&base)[2], size_t row0, size_t pitch_bytes, size_t byte0, int t) {
-        const int chunk = t & 7;
-#pragma unroll
-        for (int p = 0; p < PR::NS; ++p)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (t >> 3) + 32 * i;
-                v[p][i] = *(const u32x4*)(base[p] + (row0 + row) * pitch_bytes + byte0 + chunk * 16);
-            }
-    }
-    TG_DEVM void store(u32x4* st, int which, int t) const {
-        const int chunk = t & 7;
-#pragma unroll
-        for (int p = 0; p < PR::NS; ++p)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (t >> 3) + 32 * i;
-                st[(p * 2 + which) * TG_TILE_CHUNKS + row * 8 + tg_swz(row, chunk)] = v[p][i];
-            }
-    }
-};
-
 // ----------------------------------------------------------------------------------------------
 // K1: Ghat_partial[split] = P[c-range]^T [S|1][c-range]          (mapping_optimizer.py:201-202,:217)
-//   output tile: 128 spots x 128 genes; contraction over cells in steps of PR::BKE.
+//   output tile: TM spots x TN genes; contraction over cells in steps of PR::BKE.
 //   A operand (P^T) is produced on the fly: CH x 4 micro-blocks of M are loaded as float4 rows,
 //   exponentiated with the per-row shift/scale, transposed in registers and written to LDS
 //   as 16-byte chunks along the cell axis.  B operand comes from St (cell axis contiguous).
@@ -129,15 +137,15 @@ struct TgFwdArgs {
     const float* M;
     const float* rshift;     // [Cp] per-row softmax shift (row max); padding = +3e38
     const float* rscale;     // [Cp] per-row scale 1/Z (times the filter f_c in constrained mode); padding = 0
-    const unsigned char* St[2];
+    const unsigned char* St; // [Kp][nsteps][128 B]
     float* Gpart;            // [nsplit][Vr][Kp]
     int C, V, Vp, Vr, Kp, Cp;
-    int nkt;                 // gene tiles (Kp / 128)
+    int nkt;                 // gene tiles (Kp / TN)
     int nvt, nsplit;         // spot tiles, cell-range splits
     int nsteps;              // Cp / BKE
 };
 // grid of the forward kernel: the nkt gene tiles that share one M panel (same spot tile, same cell range) sit
-// next to each other on ONE XCD; the 8 panels in flight on an XCD belong to the same cell range and share S^T.
+// next to each other on ONE XCD; the panels in flight on an XCD belong to the same cell range and share S^T.
 TG_HD int tg_fwd_grid(int nvt, int nkt, int nsplit) { return ((nvt * nsplit + 7) / 8) * 8 * nkt; }
 TG_HD bool tg_fwd_map(int b, int nvt, int nkt, int nsplit, int& vt, int& kt, int& split) {
     const int bx = b & 7, bj = b >> 3;
@@ -148,27 +156,28 @@ TG_HD bool tg_fwd_map(int b, int nvt, int nkt, int nsplit, int& vt, int& kt, int
     return unit < nvt * nsplit;
 }
 
-template <class PR>
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
+template <class PR, class GE>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / GE::WN, wn = wave % GE::WN;
     int vt, kt, split;
     if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, a.nsplit, vt, kt, split)) return;
     const int nsplit = a.nsplit;
-    const int v0 = vt * TG_TILE, k0 = kt * TG_TILE;
+    const int v0 = vt * GE::TM, k0 = kt * GE::TN;
     const int s_begin = (int)(((long long)a.nsteps * split) / nsplit);
     const int s_end = (int)(((long long)a.nsteps * (split + 1)) / nsplit);
 
-    f32x4 acc[4][4];
+    f32x4 acc[GE::FM][GE::FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < GE::FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < GE::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // A staging: thread = (spot quad, cell chunk)
-    const int quad = t & 31, chk = t >> 5;
+    // A staging: thread = (spot quad, chunk slot of the 128-byte step row)
+    const int quad = t % (GE::TM / 4), slot = t / (GE::TM / 4);
+    const int kc = (PR::NP == 2) ? (slot & 3) : slot;          // k-chunk whose cells this thread exponentiates
     const int vcol = v0 + 4 * quad;
     const int vload = (vcol < a.Vp) ? vcol : 0;
     bool vok[4];
@@ -177,10 +186,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
 
     f32x4 mreg[PR::CH];
     float sh[PR::CH], sc[PR::CH];
-    TgKTile<PR> breg;
+    TgKTile<GE::TN, GE::NT> breg;
+    const size_t bpitch = (size_t)a.nsteps * 128;
 
     auto load_stage = [&](int step) {
-        const int cb = step * PR::BKE + chk * PR::CH;
+        const int cb = step * PR::BKE + kc * PR::CH;
 #pragma unroll
         for (int j = 0; j < PR::CH; ++j) {
             const int c = cb + j;
@@ -189,7 +199,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
             sh[j] = a.rshift[c];
             sc[j] = a.rscale[c];
         }
-        breg.load(a.St, (size_t)k0, (size_t)a.Cp * PR::ESZ, (size_t)step * PR::BKE * PR::ESZ, t);
+        breg.load(a.St, (size_t)k0, bpitch, (size_t)step, t);
     };
     auto store_stage = [&](u32x4* st) {
 #pragma unroll
@@ -203,10 +213,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
             u32x4 hi, lo;
             PR::cvt(x, hi, lo);
             const int row = 4 * quad + i;
-            st[0 * TG_TILE_CHUNKS + row * 8 + tg_swz(row, chk)] = hi;
-            if (PR::NS == 2) st[2 * TG_TILE_CHUNKS + row * 8 + tg_swz(row, chk)] = lo;
+            st[row * 8 + tg_swz(row, slot)] = (PR::NP == 2 && slot >= 4) ? lo : hi;
         }
-        breg.store(st, 1, t);
+        breg.store(st + GE::A_CHUNKS, t);
     };
 
     if (s_begin < s_end) {
@@ -214,11 +223,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
         store_stage(lds);
         __syncthreads();
         for (int s = s_begin; s < s_end; ++s) {
-            u32x4* cur = lds + ((s - s_begin) & 1) * TgStage<PR>::kChunks;
-            u32x4* nxt = lds + ((s - s_begin + 1) & 1) * TgStage<PR>::kChunks;
+            u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
+            u32x4* nxt = lds + ((s - s_begin + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < s_end;
             if (more) load_stage(s + 1);            // global loads in flight under the MFMAs
-            tg_tile_mma<PR>(cur, wm, wn, lane, acc);
+            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
             if (more) store_stage(nxt);
             __syncthreads();
         }
@@ -228,11 +237,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fwd_kernel(TgFwdArgs a) {
     float* out = a.Gpart + (size_t)split * a.Vr * a.Kp;
     const int g = lane >> 4, r15 = lane & 15;
 #pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
+    for (int fi = 0; fi < GE::FM; ++fi)
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj) {
-            const int v = v0 + wm * 64 + fi * 16 + 4 * g;
-            const int k = k0 + wn * 64 + fj * 16 + r15;
+        for (int fj = 0; fj < GE::FN; ++fj) {
+            const int v = v0 + wm * (GE::TM / GE::WM) + fi * 16 + 4 * g;
+            const int k = k0 + wn * (GE::TN / GE::WN) + fj * 16 + r15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(size_t)(v + r) * a.Kp + k] = acc[fi][fj][r];
         }
@@ -439,11 +448,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// K2d: dGhat in operand format (contraction axis = genes contiguous), rows = spots
+// K2d: dGhat in operand format (contraction axis = genes), rows = spots: [Vr][Kp/BKE steps][128 B]
 // ----------------------------------------------------------------------------------------------
 struct TgEmitArgs {
     const float* Ghat; const float* G; const float* coef; const float* vcoef;
-    unsigned char* dG[2];      // [Vr][Kp] operand elements
+    unsigned char* dG;
     int V, Vr, Kp, K;
 };
 
@@ -451,6 +460,7 @@ template <class PR>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
     const int nch = a.Kp / PR::CH;
     const int vbeg = blockIdx.x * TG_RB;
+    const size_t pitch = (size_t)(a.Kp / PR::BKE) * 128;
     for (int idx = threadIdx.x; idx < nch * TG_RB; idx += 256) {
         const int i = idx / nch, ch = idx % nch;
         const int v = vbeg + i;
@@ -465,25 +475,21 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
             const float val = (a.coef[k + e] + va) * g + (a.coef[a.Kp + k + e] + vb) * gh;
             x[e] = (k + e < a.K) ? val : 0.f;
         }
-        u32x4 hi, lo;
-        PR::cvt(x, hi, lo);
-        const size_t boff = ((size_t)v * a.Kp + k) * PR::ESZ;
-        *(u32x4*)(a.dG[0] + boff) = hi;
-        if (PR::NS == 2) *(u32x4*)(a.dG[1] + boff) = lo;
+        tg_store_operand_chunk<PR>(a.dG + (size_t)v * pitch, k / PR::BKE, (k % PR::BKE) / PR::CH, x);
     }
 }
 
 // ----------------------------------------------------------------------------------------------
 // K3: X^T tile = dGhat[v-tile] . S[c-tile]^T  (contraction over genes), fused epilogues.
 //   PHASE 1: r_part[vt][c] = sum_{v in tile} P_cv dP_cv                  (softmax backward row dot)
-//            + row partials of the entropy / L1 / L2 scalars
+//            (+ row partials of the entropy / L1 / L2 scalars and of the filter gradient when FULL)
 //   PHASE 2: dM = P (dP - r_c) [+ l1 sign(M) + 2 l2 M]; Adam; store M, m, v;
 //            (max, sum exp) partials of the NEW row for the next forward pass
-//   Fragment ownership: lane holds 4 consecutive spots (float4 of M) for cell c = lane&15.
+//   Fragment ownership: lane holds 4 consecutive spots (one float4 of M) for cell c = lane&15.
 // ----------------------------------------------------------------------------------------------
 struct TgBwdArgs {
-    const unsigned char* dG[2];   // A operand [Vr][Kp]
-    const unsigned char* Sk[2];   // B operand [Cr][Kp]
+    const unsigned char* dG;      // A operand [Vr][nsteps][128 B]
+    const unsigned char* Sk;      // B operand [Cr][nsteps][128 B]
     float* M; float* am; float* av;                // logits and Adam moments, pitch Vp
     const float* rshift; const float* rinvz;       // [Cp] softmax shift and 1/Z of the CURRENT M
     const float* fgate;                            // [C] filter f_c (constrained) or null
@@ -491,137 +497,164 @@ struct TgBwdArgs {
     const float* dens_w;                           // [C] w_c (d_source) or null (=1)
     const float* r;                                // [C] (phase 2)
     float* part;                                   // phase 1: [nvt][NP1][C]; phase 2: [nvt][2][C]
-    int C, V, Vp, Vr, Kp, nct;
-    TgTileMap map;                                 // major/minor = (cell tile, spot tile) or swapped, see map_major_is_cells
+    int C, V, Vp, Vr, Kp, nsteps;
+    TgTileMap map;                                 // major/minor = (cell tile, spot tile) or swapped
     int map_major_is_cells;
     float lambda_r, lambda_l1, lambda_l2;
     float step_size, bc2_sqrt, beta1, beta2, eps;  // Adam (phase 2)
 };
 enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
 
-template <class PR, int PHASE, bool FULL>
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_bwd_kernel(TgBwdArgs a) {
+template <class PR, class GE, int PHASE, bool FULL>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / GE::WN, wn = wave % GE::WN;
     int t_major, t_minor;
     if (!tg_tilemap(a.map, blockIdx.x, t_major, t_minor)) return;
     const int vt = a.map_major_is_cells ? t_minor : t_major, ct = a.map_major_is_cells ? t_major : t_minor;
-    const int v0 = vt * TG_TILE, c0 = ct * TG_TILE;
-    const int nsteps = a.Kp / PR::BKE;
+    const int v0 = vt * GE::TM, c0 = ct * GE::TN;
+    const int nsteps = a.nsteps;
 
-    f32x4 acc[4][4];
+    f32x4 acc[GE::FM][GE::FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < GE::FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < GE::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TgKTile<PR> ra, rb;
-    const size_t pitch = (size_t)a.Kp * PR::ESZ;
-    ra.load(a.dG, (size_t)v0, pitch, 0, t);
-    rb.load(a.Sk, (size_t)c0, pitch, 0, t);
-    ra.store(lds, 0, t);
-    rb.store(lds, 1, t);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        u32x4* cur = lds + (s & 1) * TgStage<PR>::kChunks;
-        u32x4* nxt = lds + ((s + 1) & 1) * TgStage<PR>::kChunks;
-        const bool more = (s + 1) < nsteps;
-        if (more) {
-            const size_t b0 = (size_t)(s + 1) * PR::BKE * PR::ESZ;
-            ra.load(a.dG, (size_t)v0, pitch, b0, t);
-            rb.load(a.Sk, (size_t)c0, pitch, b0, t);
-        }
-        tg_tile_mma<PR>(cur, wm, wn, lane, acc);
-        if (more) { ra.store(nxt, 0, t); rb.store(nxt, 1, t); }
+    {
+        TgKTile<GE::TM, GE::NT> ra;
+        TgKTile<GE::TN, GE::NT> rb;
+        const size_t pitch = (size_t)nsteps * 128;
+        ra.load(a.dG, (size_t)v0, pitch, 0, t);
+        rb.load(a.Sk, (size_t)c0, pitch, 0, t);
+        ra.store(lds, t);
+        rb.store(lds + GE::A_CHUNKS, t);
         __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
+            u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
+            const bool more = (s + 1) < nsteps;
+            if (more) {
+                ra.load(a.dG, (size_t)v0, pitch, (size_t)(s + 1), t);
+                rb.load(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), t);
+            }
+            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
+            if (more) { ra.store(nxt, t); rb.store(nxt + GE::A_CHUNKS, t); }
+            __syncthreads();
+        }
     }
 
     // ---------------- epilogue ----------------
-    float* red = (float*)tg_lds;        // reuse LDS (all waves are past the last barrier)
+    float* red = (float*)tg_lds;        // LDS reuse: every wave is past the last barrier of the main loop
     const int g = lane >> 4, r15 = lane & 15;
     constexpr int NP = (PHASE == 1) ? (FULL ? (int)TGP1_N : 1) : 2;
-    float pacc[4][NP];
+    constexpr int FM = GE::FM, FN = GE::FN;
+    constexpr int EB = 2;                                      // spot quads whose global loads are issued together
+    const int vbase = v0 + wm * (GE::TM / GE::WM) + 4 * g;      // + fi * 16
+    float pacc[FN][NP];
 
 #pragma unroll
-    for (int fj = 0; fj < 4; ++fj) {
-        const int c = c0 + wn * 64 + fj * 16 + r15;
+    for (int fj = 0; fj < FN; ++fj) {
+        const int c = c0 + wn * (GE::TN / GE::WN) + fj * 16 + r15;
         const bool cok = c < a.C;
         const int cc = cok ? c : a.C - 1;
         const float sh = a.rshift[cc], iz = a.rinvz[cc];
         const float fg = a.fgate ? a.fgate[cc] : 1.f;
         const float wc = a.dens_w ? a.dens_w[cc] : 1.f;
+        const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
         if constexpr (PHASE == 1) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) pacc[fj][q] = 0.f;
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi) {
-                const int v = v0 + wm * 64 + fi * 16 + 4 * g;
-                if (v >= a.Vp) continue;
-                const f32x4 mq = *(const f32x4*)(a.M + (size_t)cc * a.Vp + v);
-                const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + v);
+            for (int fb = 0; fb < FM; fb += EB) {
+                f32x4 mq[EB], aq[EB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (cok && (v + e) < a.V) {
-                        const float p = tg_exp(mq[e] - sh) * iz;
-                        const float x = acc[fi][fj][e];
-                        float dp = fg * (x + aq[e] * wc);
-                        if (FULL) {
-                            if (a.lambda_r != 0.f) {
-                                const float lp = (mq[e] - sh) + tg_log(iz);      // log P, no underflow
-                                dp -= a.lambda_r * (lp + 1.f);
-                                pacc[fj][TGP1_ENT % NP] += p * lp;
+                for (int f = 0; f < EB; ++f) {                 // issue the loads of this batch together
+                    const int v = vbase + (fb + f) * 16;
+                    mq[f] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + (v < a.Vp ? v : 0));
+                    aq[f] = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
+                }
+#pragma unroll
+                for (int f = 0; f < EB; ++f) {
+                    const int fi = fb + f, v = vbase + fi * 16;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (cok && (v + e) < a.V) {
+                            const float p = tg_exp(mq[f][e] - sh) * iz;
+                            const float x = acc[fi][fj][e];
+                            float dp = fg * (x + aq[f][e] * wc);
+                            if (FULL) {
+                                if (a.lambda_r != 0.f) {
+                                    const float lp = (mq[f][e] - sh) + logiz;      // log P, no underflow
+                                    dp -= a.lambda_r * (lp + 1.f);
+                                    pacc[fj][TGP1_ENT % NP] += p * lp;
+                                }
+                                pacc[fj][TGP1_Q % NP] += p * x;
+                                pacc[fj][TGP1_PA % NP] += p * aq[f][e];
+                                pacc[fj][TGP1_L1 % NP] += fabsf(mq[f][e]);
+                                pacc[fj][TGP1_L2 % NP] += mq[f][e] * mq[f][e];
                             }
-                            pacc[fj][TGP1_Q % NP] += p * x;
-                            pacc[fj][TGP1_PA % NP] += p * aq[e];
-                            pacc[fj][TGP1_L1 % NP] += fabsf(mq[e]);
-                            pacc[fj][TGP1_L2 % NP] += mq[e] * mq[e];
+                            pacc[fj][TGP1_R] += p * dp;
                         }
-                        pacc[fj][TGP1_R] += p * dp;
                     }
                 }
             }
         } else {
             const float rc = a.r[cc];
-            float nm[16];
-            float lmax = TG_NEG_BIG;
+            float lmax = TG_NEG_BIG, lsum = 0.f;               // online (max, sum exp) of the new logits
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi) {
-                const int v = v0 + wm * 64 + fi * 16 + 4 * g;
-                const bool qok = cok && (v < a.Vp);
-                const size_t off = (size_t)cc * a.Vp + (qok ? v : 0);
-                f32x4 mq = *(const f32x4*)(a.M + off);
-                f32x4 m1 = *(const f32x4*)(a.am + off);
-                f32x4 m2 = *(const f32x4*)(a.av + off);
-                const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
+            for (int fb = 0; fb < FM; fb += EB) {
+                f32x4 mq[EB], m1[EB], m2[EB], aq[EB];
+                size_t off[EB];
+                bool qok[EB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = qok && (v + e) < a.V;
-                    const float mo = mq[e];
-                    const float p = tg_exp(mo - sh) * iz;
-                    float dp = fg * (acc[fi][fj][e] + aq[e] * wc);
-                    if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + tg_log(iz) + 1.f);
-                    float gm = p * (dp - rc);
-                    if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
-                    if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
-                    // torch.optim.Adam (_single_tensor_adam): lerp, mul+addcmul, sqrt/bc2 + eps, addcdiv
-                    const float e1 = m1[e] + (gm - m1[e]) * (1.f - a.beta1);
-                    const float e2 = m2[e] * a.beta2 + (1.f - a.beta2) * gm * gm;
-                    const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
-                    const float mn = mo - a.step_size * (e1 / den);
-                    if (ok) { mq[e] = mn; m1[e] = e1; m2[e] = e2; lmax = tg_fmax(lmax, mn); }
-                    nm[fi * 4 + e] = ok ? mn : TG_NEG_BIG;
+                for (int f = 0; f < EB; ++f) {                 // the loads of a batch are in flight together
+                    const int v = vbase + (fb + f) * 16;
+                    qok[f] = cok && (v < a.Vp);
+                    off[f] = (size_t)cc * a.Vp + (qok[f] ? v : 0);
+                    mq[f] = *(const f32x4*)(a.M + off[f]);
+                    m1[f] = *(const f32x4*)(a.am + off[f]);
+                    m2[f] = *(const f32x4*)(a.av + off[f]);
+                    aq[f] = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
                 }
-                if (qok) {
-                    *(f32x4*)(a.M + off) = mq;
-                    *(f32x4*)(a.am + off) = m1;
-                    *(f32x4*)(a.av + off) = m2;
+#pragma unroll
+                for (int f = 0; f < EB; ++f) {
+                    const int fi = fb + f, v = vbase + fi * 16;
+                    float nm[4];
+                    float qmax = TG_NEG_BIG;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = qok[f] && (v + e) < a.V;
+                        const float mo = mq[f][e];
+                        const float p = tg_exp(mo - sh) * iz;
+                        float dp = fg * (acc[fi][fj][e] + aq[f][e] * wc);
+                        if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + logiz + 1.f);
+                        float gm = p * (dp - rc);
+                        if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
+                        if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
+                        // torch.optim.Adam (_single_tensor_adam): lerp, mul+addcmul, sqrt/bc2 + eps, addcdiv
+                        const float e1 = m1[f][e] + (gm - m1[f][e]) * (1.f - a.beta1);
+                        const float e2 = m2[f][e] * a.beta2 + (1.f - a.beta2) * gm * gm;
+                        const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
+                        const float mn = mo - a.step_size * (e1 / den);
+                        if (ok) { mq[f][e] = mn; m1[f][e] = e1; m2[f][e] = e2; qmax = tg_fmax(qmax, mn); }
+                        nm[e] = ok ? mn : TG_NEG_BIG;
+                    }
+                    if (qok[f]) {
+                        *(f32x4*)(a.M + off[f]) = mq[f];
+                        *(f32x4*)(a.am + off[f]) = m1[f];
+                        *(f32x4*)(a.av + off[f]) = m2[f];
+                    }
+                    const float nmx = tg_fmax(lmax, qmax);
+                    float qs = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qs += (nm[e] > TG_NEG_BIG) ? tg_exp(nm[e] - nmx) : 0.f;
+                    lsum = lsum * tg_exp(lmax - nmx) + qs;
+                    lmax = nmx;
                 }
             }
-            float lsum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) lsum += (nm[i] > TG_NEG_BIG) ? tg_exp(nm[i] - lmax) : 0.f;
             pacc[fj][0] = lmax;
             pacc[fj][1] = lsum;
         }
@@ -644,28 +677,36 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_bwd_kernel(TgBwdArgs a) {
             }
         }
     }
-    // combine the two waves along the spot axis through LDS, then one store per cell
-    __syncthreads();                       // all MFMA reads of LDS are done before reuse
+    // combine the WM waves along the spot axis through LDS, then one store per cell
+    __syncthreads();
     if (g == 0) {
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj)
+        for (int fj = 0; fj < FN; ++fj)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) red[((wm * NP + q) * TG_TILE) + wn * 64 + fj * 16 + r15] = pacc[fj][q];
+            for (int q = 0; q < NP; ++q)
+                red[((wm * NP + q) * GE::TN) + wn * (GE::TN / GE::WN) + fj * 16 + r15] = pacc[fj][q];
     }
     __syncthreads();
-    if (t < TG_TILE) {
+    if (t < GE::TN) {
         const int c = c0 + t;
         if (c < a.C) {
             if constexpr (PHASE == 1) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    a.part[((size_t)vt * NP + q) * a.C + c] = red[(0 * NP + q) * TG_TILE + t] + red[(1 * NP + q) * TG_TILE + t];
+                for (int q = 0; q < NP; ++q) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < GE::WM; ++w) sum += red[(w * NP + q) * GE::TN + t];
+                    a.part[((size_t)vt * NP + q) * a.C + c] = sum;
+                }
             } else {
-                const float m0 = red[(0 * NP + 0) * TG_TILE + t], s0 = red[(0 * NP + 1) * TG_TILE + t];
-                const float m1 = red[(1 * NP + 0) * TG_TILE + t], s1 = red[(1 * NP + 1) * TG_TILE + t];
-                const float mx = tg_fmax(m0, m1);
+                float mx = TG_NEG_BIG;
+#pragma unroll
+                for (int w = 0; w < GE::WM; ++w) mx = tg_fmax(mx, red[(w * NP + 0) * GE::TN + t]);
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < GE::WM; ++w) sum += red[(w * NP + 1) * GE::TN + t] * tg_exp(red[(w * NP + 0) * GE::TN + t] - mx);
                 a.part[((size_t)vt * 2 + 0) * a.C + c] = mx;
-                a.part[((size_t)vt * 2 + 1) * a.C + c] = s0 * tg_exp(m0 - mx) + s1 * tg_exp(m1 - mx);
+                a.part[((size_t)vt * 2 + 1) * a.C + c] = sum;
             }
         }
     }
@@ -846,8 +887,8 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_softmax_out(const float* M, const float*
 struct TgPrepSArgs {
     const float* S; int C, K;           // caller's [C][K]
     const float* aug;                   // [C] values of the augmentation column (null => 1)
-    unsigned char* Sk[2]; int Cr, Kp;   // [Cr][Kp]
-    unsigned char* St[2]; int Cp;       // [Kp][Cp]
+    unsigned char* Sk; int Cr, Kp;      // [Cr][Kp/BKE][128 B]   (contraction over genes)
+    unsigned char* St; int Cp;          // [Kp][Cp/BKE][128 B]   (contraction over cells)
 };
 TG_DEV float tg_s_aug(const TgPrepSArgs& a, int c, int k) {
     if (c >= a.C) return 0.f;
@@ -861,14 +902,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_sk(TgPrepSArgs a) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)a.Cr * nch) return;
     const int c = (int)(idx / nch), ch = (int)(idx % nch);
+    const int k = ch * PR::CH;
     float x[PR::CH];
 #pragma unroll
-    for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, c, ch * PR::CH + e);
-    u32x4 hi, lo;
-    PR::cvt(x, hi, lo);
-    const size_t boff = ((size_t)c * a.Kp + (size_t)ch * PR::CH) * PR::ESZ;
-    *(u32x4*)(a.Sk[0] + boff) = hi;
-    if (PR::NS == 2) *(u32x4*)(a.Sk[1] + boff) = lo;
+    for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, c, k + e);
+    tg_store_operand_chunk<PR>(a.Sk + (size_t)c * (a.Kp / PR::BKE) * 128, k / PR::BKE, (k % PR::BKE) / PR::CH, x);
 }
 template <class PR>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_st(TgPrepSArgs a) {
@@ -876,14 +914,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_st(TgPrepSArgs a) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)a.Kp * nch) return;
     const int k = (int)(idx % a.Kp), ch = (int)(idx / a.Kp);     // k fastest: coalesced reads of S rows
+    const int c = ch * PR::CH;
     float x[PR::CH];
 #pragma unroll
-    for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, ch * PR::CH + e, k);
-    u32x4 hi, lo;
-    PR::cvt(x, hi, lo);
-    const size_t boff = ((size_t)k * a.Cp + (size_t)ch * PR::CH) * PR::ESZ;
-    *(u32x4*)(a.St[0] + boff) = hi;
-    if (PR::NS == 2) *(u32x4*)(a.St[1] + boff) = lo;
+    for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, c + e, k);
+    tg_store_operand_chunk<PR>(a.St + (size_t)k * (a.Cp / PR::BKE) * 128, c / PR::BKE, (c % PR::BKE) / PR::CH, x);
 }
 
 // Gp = zero-padded copy of G; vnorm2[v] = sum_k G^2; gnormpart[rb][k] = partial sum_v G^2

@@ -28,7 +28,7 @@ def shard_bounds(n, world, rank):
 
 class ShardedMapperEngine:
     def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, *, n_spots_total, device, precision="bf16x3",
-                 lambdas=None, group=None, fwd_splits=0):
+                 lambdas=None, group=None, fwd_splits=0, tile_size=0):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -36,7 +36,7 @@ class ShardedMapperEngine:
         self.lam.update(lambdas or {})
         self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, device=device,
                                    precision=precision, lambdas=self.lam, n_spots_total=n_spots_total,
-                                   fwd_splits=fwd_splits)
+                                   fwd_splits=fwd_splits, tile_size=tile_size)
         self.has_density = d_local is not None
         e = self.eng
         self.x_gene = e.exchange_buffer(_capi.X_GENESTAT)

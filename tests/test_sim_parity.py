@@ -48,3 +48,27 @@ def test_emulated_forward_splits_agree(sim):
     ref = orc.softmax_rows(M0.astype(np.float64)).T @ data["S"].astype(np.float64)
     for o in outs:
         assert np.linalg.norm(o - ref) / np.linalg.norm(ref) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
+def test_emulated_large_tile_geometry(sim, precision):
+    """Force the 256 x 256 / 512-thread geometry on a small ragged problem and compare one step with the oracle."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V = 300, 40, 270            # 2 x 2 tiles of 256, ragged
+    data = orc.make_synthetic(C, K, V, seed=9)
+    M0 = orc.reference_init_M(C, V, 4)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_r=1e-3)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision=precision, lambdas=lam, tile_size=256)
+    n = 2
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(n, 0.1)
+    tol = pc.TOL[precision]
+    from tangram_amd import _capi
+    for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss"), (_capi.H_VG, "vg_reg"),
+                   (_capi.H_KL, "kl_reg"), (_capi.H_ENTROPY, "entropy_reg")):
+        scale = max(1.0, abs(ho[k][0]))
+        np.testing.assert_allclose(hist[:, col].numpy(), np.array(ho[k]), atol=tol["loss"] * scale, rtol=0, err_msg=k)
+    assert np.abs(e.result().numpy() - Po).max() < tol["P"]
