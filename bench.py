@@ -35,10 +35,10 @@ def kernel_model(name, C, K, V):
     small = 4.0 * (C * K + V * K)
     if name == "tg_fwd_kernel":
         return 4.0 * C * V + small, gemm            # read M once, S once, write Ghat
-    if name == "tg_bwd_kernel<rowdot>":
-        return 4.0 * C * V + small, gemm            # read M once, S and dGhat once
-    if name == "tg_bwd_kernel<update>":
-        return 24.0 * C * V + small, gemm           # read+write M, Adam m, Adam v
+    if name == "tg_bwd_kernel":
+        return 4.0 * C * V + small, gemm            # read M once, S and dGhat once (the stored X is implementation traffic)
+    if name == "tg_adam_update":
+        return 24.0 * C * V, 0.0                    # read+write M, Adam m, Adam v
     return None, None
 
 

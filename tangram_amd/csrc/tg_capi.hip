@@ -56,7 +56,7 @@ static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
     size_t o_Sk, o_St, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
-        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, total;
+        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X, total;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
@@ -123,11 +123,12 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_fgate = take((size_t)L->Cp * 4);
     L->o_densw = take((size_t)L->Cp * 4);
     const size_t np1 = L->full ? TGP1_N : 1;
-    L->o_part = take((size_t)L->nvt * (np1 > 2 ? np1 : 2) * L->C * 4);
+    L->o_part = take((size_t)L->nvt * np1 * L->C * 4);
     L->o_rowq = take((size_t)TGP1_N * L->C * 4);
     L->o_rowpair = take((size_t)2 * L->C * 4);
     L->o_scal = take(64 * 4);
     L->o_fsum = take(64 * 4);
+    L->o_X = take((size_t)L->C * L->Vp * 4);
     L->total = off;
     size_t so = 0;
     auto stake = [&](size_t bytes) { size_t o = so; so += rup(bytes, 256); return o; };
@@ -190,10 +191,8 @@ static int tg_lds_attr() {
 #ifndef TG_SIM
     const int bytes = GE::LDS_BYTES;
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 #endif
     return TG_OK;
 }
@@ -373,12 +372,11 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     const TgLayout& L = m->L;
     a.dG = m->ws + L.o_dG;
     a.Sk = m->ws + L.o_Sk;
-    a.M = (float*)(m->st + L.s_M); a.am = (float*)(m->st + L.s_m1); a.av = (float*)(m->st + L.s_m2);
+    a.M = (const float*)(m->st + L.s_M); a.X = m->fp(L.o_X);
     a.rshift = m->fp(L.o_rshift); a.rinvz = m->fp(L.o_rinvz);
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     a.vcoef = m->fp(L.o_vcoef);
     a.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
-    a.r = m->fp(L.o_rowq);
     a.part = m->fp(L.o_part);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nsteps = L.Kp / PR::BKE;
     // XCD bands along the longer tile axis when it is long enough to feed 8 XCDs, otherwise a plain linear order
@@ -386,19 +384,18 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, L.nct}; a.map_major_is_cells = 0; }
     else { a.map = TgTileMap{0, L.nvt, L.nct}; a.map_major_is_cells = 0; }
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
-    a.step_size = 0.f; a.bc2_sqrt = 1.f; a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
 }
 
-template <class PR, int PHASE>
+template <class PR>
 static void tg_launch_bwd(tg_mapper* m, const TgBwdArgs& a) {
     const TgLayout& L = m->L;
     const int grid = tg_tilemap_grid(a.map);
     if (L.T == 256) {
-        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, PHASE, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, PHASE, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
+        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
     } else {
-        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, PHASE, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, PHASE, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
+        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
     }
 }
 
@@ -407,8 +404,8 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
     TgBwdArgs a;
     tg_fill_bwd<PR>(m, a);
-    tg_launch_bwd<PR, 1>(m, a);
-    tg_prof_mark(m, "tg_bwd_kernel<rowdot>");
+    tg_launch_bwd<PR>(m, a);
+    tg_prof_mark(m, "tg_bwd_kernel");
     TgRowsumArgs r;
     r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
     TG_LAUNCH(tg_rowsum_parts, (L.C + 255) / 256, 1, 256, 0, m->stream, r);
@@ -424,18 +421,27 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     return TG_OK;
 }
 
-template <class PR>
-static int tg_launch_update(tg_mapper* m, float lr) {
+// streaming softmax-backward + Adam; `finalize`: write the next softmax statistics directly (single GPU, no filter)
+static int tg_launch_update(tg_mapper* m, float lr, bool finalize) {
     const TgLayout& L = m->L;
-    TgBwdArgs a;
-    tg_fill_bwd<PR>(m, a);
+    TgUpdateArgs u;
+    u.X = m->fp(L.o_X);
+    u.M = (float*)(m->st + L.s_M); u.am = (float*)(m->st + L.s_m1); u.av = (float*)(m->st + L.s_m2);
+    u.rshift = m->fp(L.o_rshift); u.rinvz = m->fp(L.o_rinvz);
+    u.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
+    u.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
+    u.vcoef = m->fp(L.o_vcoef); u.r = m->fp(L.o_rowq);
+    u.pair_out = m->fp(L.o_rowpair);
+    u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_scale = m->fp(L.o_rscale);
+    u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0;
+    u.lambda_r = m->cfg.lambda_r; u.lambda_l1 = m->cfg.lambda_l1; u.lambda_l2 = m->cfg.lambda_l2;
     const double t = (double)(m->step + 1);
-    const double bc1 = 1.0 - pow((double)m->cfg.beta1, t);
-    const double bc2 = 1.0 - pow((double)m->cfg.beta2, t);
-    a.step_size = (float)((double)lr / bc1);
-    a.bc2_sqrt = (float)sqrt(bc2);
-    tg_launch_bwd<PR, 2>(m, a);
-    tg_prof_mark(m, "tg_bwd_kernel<update>");
+    u.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
+    u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
+    u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
+    if (L.full) TG_LAUNCH((tg_adam_update<true>), L.C, 1, 256, 64, m->stream, u);
+    else TG_LAUNCH((tg_adam_update<false>), L.C, 1, 256, 64, m->stream, u);
+    tg_prof_mark(m, "tg_adam_update");
     return TG_OK;
 }
 
@@ -446,9 +452,12 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
     if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
-    if ((rc = tg_launch_update<PR>(m, lr))) return rc;
-    if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
-    if ((rc = tg_merge(m, m->fp(m->L.o_part), m->L.nvt, true, false))) return rc;
+    const bool constrained = (m->cfg.mode == TG_MODE_CONSTRAINED);
+    if ((rc = tg_launch_update(m, lr, !constrained))) return rc;
+    if (constrained) {      // Adam on F, then fold the NEW filter into the forward row scale
+        if ((rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
+        if ((rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false))) return rc;
+    }
     m->step += 1;
     TG_CK(tg_check_launch());
     return TG_OK;
@@ -488,9 +497,8 @@ static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, con
             rc = tg_launch_rowdots<PR>(m, hist_row);
             break;
         case 3:
-            if ((rc = tg_launch_update<PR>(m, lr))) return rc;
+            if ((rc = tg_launch_update(m, lr, false))) return rc;      // leaves the local (max, Z) pairs in TG_X_ROWPAIR
             if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
-            rc = tg_merge(m, m->fp(L.o_part), L.nvt, false, true);
             m->step += 1;
             break;
         case 4:

@@ -481,32 +481,33 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
 
 // ----------------------------------------------------------------------------------------------
 // K3: X^T tile = dGhat[v-tile] . S[c-tile]^T  (contraction over genes), fused epilogues.
-//   PHASE 1: r_part[vt][c] = sum_{v in tile} P_cv dP_cv                  (softmax backward row dot)
-//            (+ row partials of the entropy / L1 / L2 scalars and of the filter gradient when FULL)
-//   PHASE 2: dM = P (dP - r_c) [+ l1 sign(M) + 2 l2 M]; Adam; store M, m, v;
-//            (max, sum exp) partials of the NEW row for the next forward pass
+//   epilogue: X[c][v] stored (fp32) for the update kernel, and
+//             r_part[vt][c] = sum_{v in tile} P_cv dP_cv                 (softmax backward row dot)
+//             (+ row partials of the entropy / L1 / L2 scalars and of the filter gradient when FULL)
+//   Softmax backward needs the complete row dot r_c before any element of the row can be updated, so the
+//   update runs as a second, purely streaming kernel (tg_adam_update) on the stored X.
 //   Fragment ownership: lane holds 4 consecutive spots (one float4 of M) for cell c = lane&15.
 // ----------------------------------------------------------------------------------------------
 struct TgBwdArgs {
     const unsigned char* dG;      // A operand [Vr][nsteps][128 B]
     const unsigned char* Sk;      // B operand [Cr][nsteps][128 B]
-    float* M; float* am; float* av;                // logits and Adam moments, pitch Vp
+    const float* M;                                // logits, pitch Vp
+    float* X;                                      // [C][Vp] backward GEMM result S dGhat^T (consumed by tg_adam_update)
     const float* rshift; const float* rinvz;       // [Cp] softmax shift and 1/Z of the CURRENT M
     const float* fgate;                            // [C] filter f_c (constrained) or null
     const float* vcoef;                            // a_v at [2*Vr + v]
     const float* dens_w;                           // [C] w_c (d_source) or null (=1)
-    const float* r;                                // [C] (phase 2)
-    float* part;                                   // phase 1: [nvt][NP1][C]; phase 2: [nvt][2][C]
+    float* part;                                   // [nvt][NP1][C] row-dot partials
     int C, V, Vp, Vr, Kp, nsteps;
     TgTileMap map;                                 // major/minor = (cell tile, spot tile) or swapped
     int map_major_is_cells;
     float lambda_r, lambda_l1, lambda_l2;
-    float step_size, bc2_sqrt, beta1, beta2, eps;  // Adam (phase 2)
 };
 enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
 
-template <class PR, class GE, int PHASE, bool FULL>
+template <class PR, class GE, bool FULL>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
+    constexpr int PHASE = 1;
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
@@ -579,6 +580,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
 #pragma unroll
                 for (int f = 0; f < EB; ++f) {
                     const int fi = fb + f, v = vbase + fi * 16;
+                    if (cok && v < a.Vp) *(f32x4*)(a.X + (size_t)cc * a.Vp + v) = acc[fi][fj];   // X = S dGhat^T, kept for the update
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (cok && (v + e) < a.V) {
@@ -601,62 +603,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
                     }
                 }
             }
-        } else {
-            const float rc = a.r[cc];
-            float lmax = TG_NEG_BIG, lsum = 0.f;               // online (max, sum exp) of the new logits
-#pragma unroll
-            for (int fb = 0; fb < FM; fb += EB) {
-                f32x4 mq[EB], m1[EB], m2[EB], aq[EB];
-                size_t off[EB];
-                bool qok[EB];
-#pragma unroll
-                for (int f = 0; f < EB; ++f) {                 // the loads of a batch are in flight together
-                    const int v = vbase + (fb + f) * 16;
-                    qok[f] = cok && (v < a.Vp);
-                    off[f] = (size_t)cc * a.Vp + (qok[f] ? v : 0);
-                    mq[f] = *(const f32x4*)(a.M + off[f]);
-                    m1[f] = *(const f32x4*)(a.am + off[f]);
-                    m2[f] = *(const f32x4*)(a.av + off[f]);
-                    aq[f] = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
-                }
-#pragma unroll
-                for (int f = 0; f < EB; ++f) {
-                    const int fi = fb + f, v = vbase + fi * 16;
-                    float nm[4];
-                    float qmax = TG_NEG_BIG;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool ok = qok[f] && (v + e) < a.V;
-                        const float mo = mq[f][e];
-                        const float p = tg_exp(mo - sh) * iz;
-                        float dp = fg * (acc[fi][fj][e] + aq[f][e] * wc);
-                        if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + logiz + 1.f);
-                        float gm = p * (dp - rc);
-                        if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
-                        if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
-                        // torch.optim.Adam (_single_tensor_adam): lerp, mul+addcmul, sqrt/bc2 + eps, addcdiv
-                        const float e1 = m1[f][e] + (gm - m1[f][e]) * (1.f - a.beta1);
-                        const float e2 = m2[f][e] * a.beta2 + (1.f - a.beta2) * gm * gm;
-                        const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
-                        const float mn = mo - a.step_size * (e1 / den);
-                        if (ok) { mq[f][e] = mn; m1[f][e] = e1; m2[f][e] = e2; qmax = tg_fmax(qmax, mn); }
-                        nm[e] = ok ? mn : TG_NEG_BIG;
-                    }
-                    if (qok[f]) {
-                        *(f32x4*)(a.M + off[f]) = mq[f];
-                        *(f32x4*)(a.am + off[f]) = m1[f];
-                        *(f32x4*)(a.av + off[f]) = m2[f];
-                    }
-                    const float nmx = tg_fmax(lmax, qmax);
-                    float qs = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) qs += (nm[e] > TG_NEG_BIG) ? tg_exp(nm[e] - nmx) : 0.f;
-                    lsum = lsum * tg_exp(lmax - nmx) + qs;
-                    lmax = nmx;
-                }
-            }
-            pacc[fj][0] = lmax;
-            pacc[fj][1] = lsum;
         }
         // reduce over the 4 lane groups holding the same cell (different spots)
         if constexpr (PHASE == 1) {
@@ -708,6 +654,97 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
                 a.part[((size_t)vt * 2 + 0) * a.C + c] = mx;
                 a.part[((size_t)vt * 2 + 1) * a.C + c] = sum;
             }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K4: streaming softmax-backward + Adam (mapping_optimizer.py:394-396; torch _single_tensor_adam).
+//   One workgroup per cell (row of M): dM = P (dP - r_c) [+ l1 sign(M) + 2 l2 M], Adam, store M, m, v,
+//   and the (max, sum exp) of the NEW row for the next forward pass.  Pure HBM stream:
+//   reads X, M, m, v (16 B / element), writes M, m, v (12 B / element); algorithmic traffic 24 B / element.
+// ----------------------------------------------------------------------------------------------
+struct TgUpdateArgs {
+    const float* X; float* M; float* am; float* av;   // [C][Vp]
+    const float* rshift; const float* rinvz;          // softmax statistics of the CURRENT M
+    const float* fgate; const float* dens_w;          // [C] or null
+    const float* vcoef;                               // a_v at [2*Vr + v]
+    const float* r;                                   // [C] row dots
+    float* pair_out;                                  // [2][C] (max, Z) of the new row (cross-GPU exchange)
+    float* new_shift; float* new_invz; float* new_scale;   // finalised statistics (single GPU) or null
+    int C, V, Vp, Vr, finalize;
+    float lambda_r, lambda_l1, lambda_l2;
+    float step_size, bc2_sqrt, beta1, beta2, eps;
+};
+
+template <bool FULL>
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;          // [4 waves][2]
+    const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float sh = a.rshift[c], iz = a.rinvz[c], rc = a.r[c];
+    const float fg = a.fgate ? a.fgate[c] : 1.f;
+    const float wc = a.dens_w ? a.dens_w[c] : 1.f;
+    const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
+    const size_t row = (size_t)c * a.Vp;
+    float lmax = TG_NEG_BIG, lsum = 0.f;
+    for (int v = 4 * t; v < a.V; v += 1024) {
+        const f32x4 xq = *(const f32x4*)(a.X + row + v);
+        f32x4 mq = *(const f32x4*)(a.M + row + v);
+        f32x4 m1 = *(const f32x4*)(a.am + row + v);
+        f32x4 m2 = *(const f32x4*)(a.av + row + v);
+        const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + v);
+        float nm[4];
+        float qmax = TG_NEG_BIG;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = (v + e) < a.V;
+            const float mo = mq[e];
+            const float p = tg_exp(mo - sh) * iz;
+            float dp = fg * (xq[e] + aq[e] * wc);
+            if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + logiz + 1.f);
+            float gm = p * (dp - rc);
+            if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
+            if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
+            // exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/bc2 + eps; p.addcdiv_(m, denom, -step)
+            const float e1 = m1[e] + (gm - m1[e]) * (1.f - a.beta1);
+            const float e2 = m2[e] * a.beta2 + (1.f - a.beta2) * gm * gm;
+            const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
+            const float mn = mo - a.step_size * (e1 / den);
+            if (ok) { mq[e] = mn; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mn); }
+            nm[e] = ok ? mn : TG_NEG_BIG;
+        }
+        *(f32x4*)(a.M + row + v) = mq;
+        *(f32x4*)(a.am + row + v) = m1;
+        *(f32x4*)(a.av + row + v) = m2;
+        const float nmx = tg_fmax(lmax, qmax);
+        float qs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qs += (nm[e] > TG_NEG_BIG) ? tg_exp(nm[e] - nmx) : 0.f;
+        lsum = lsum * tg_exp(lmax - nmx) + qs;
+        lmax = nmx;
+    }
+    // (max, sum exp) of the whole new row: wave shuffle tree, then the 4 waves through LDS (fixed order)
+#pragma unroll
+    for (int msk = 1; msk <= 32; msk <<= 1) {
+        const float om = tg_shfl_xor(lmax, msk), os = tg_shfl_xor(lsum, msk);
+        const float nmx = tg_fmax(lmax, om);
+        lsum = lsum * tg_exp(lmax - nmx) + os * tg_exp(om - nmx);
+        lmax = nmx;
+    }
+    if (lane == 0) { red[wave * 2] = lmax; red[wave * 2 + 1] = lsum; }
+    __syncthreads();
+    if (t == 0) {
+        float mx = tg_fmax(tg_fmax(red[0], red[2]), tg_fmax(red[4], red[6]));
+        float z = 0.f;
+        for (int w = 0; w < 4; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
+        a.pair_out[c] = mx;
+        a.pair_out[a.C + c] = z;
+        if (a.finalize) {
+            const float inz = 1.f / z;
+            a.new_shift[c] = mx;
+            a.new_invz[c] = inz;
+            a.new_scale[c] = inz;      // the constrained filter is folded in afterwards by tg_merge_stats
         }
     }
 }

@@ -58,7 +58,7 @@ class ShardedMapperEngine:
         dist.all_reduce(self.x_gene, group=self.group)
         e.phase(2, history_row=history_row)
         dist.all_reduce(self.x_rowq, group=self.group)
-        e.phase(3, lr=lr)
+        e.phase(3, lr=lr, history_row=history_row)
         self._exchange_row_stats()
 
     def run(self, n_steps, lr, history=None, first_row=0):
