@@ -15,9 +15,11 @@ fi
 for P in bf16x3 bf16 fp32; do
   echo "== bench $P"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
 done
-for P in bf16x3; do
-  echo "== bench $P tile128"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --tile 128 --no-cpu-baseline > $O/bench_${P}_t128.json 2> $O/bench_${P}_t128.err; echo "rc=$?"
+if [ -f $R/build/libtangram_hip_alt.so ]; then
+for P in bf16x3 bf16; do
+  echo "== bench $P ALT lib"; TANGRAM_AMD_LIB=$R/build/libtangram_hip_alt.so timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline > $O/bench_${P}_alt.json 2> $O/bench_${P}_alt.err; echo "rc=$?"
 done
+fi
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp
 for P in bf16x3 bf16; do

@@ -46,6 +46,10 @@ TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) {
     return f32x4{t[0], t[1], t[2], t[3]};
 }
 TG_DEV float tg_atomic_add(float* p, float v) { float o = *p; *p = o + v; return o; }
+// global -> LDS DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane * 16
+TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
+    memcpy(lds_wave_base + 16 * hipsim::lane_id(), src, 16);
+}
 #else
 // ------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
@@ -79,6 +83,16 @@ TG_DEV f32x4 tg_mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 // v_mfma_f32_16x16x4_f32: lane l holds A[row=l&15][k=l>>4], B[k=l>>4][col=l&15]; exact f32 fmaf chain.
 TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 TG_DEV float tg_atomic_add(float* p, float v) { return atomicAdd(p, v); }
+// global_load_lds_dwordx4: asynchronous global -> LDS copy that bypasses the VGPRs; the LDS destination is
+// M0 (wave-uniform base) + lane * 16, the global source address is per lane.  Completion is tracked by vmcnt;
+// hipcc drains it before the next __syncthreads().
+TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#endif
+#ifndef TG_GLDS
+#define TG_GLDS 1          // 1: K-contiguous operand tiles are staged with global_load_lds; 0: through registers
 #endif
 
 TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }

@@ -105,6 +105,19 @@ struct TgKTile {
     }
 };
 
+// The same slab copied by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.  The LDS image of one
+// wave instruction is lane-linear (64 x 16 B = 8 tile rows), so the XOR swizzle is applied to the per-lane SOURCE
+// address (logical chunk = physical chunk ^ swizzle(row)), the read side applies the same involution.
+template <int ROWS, int NT>
+TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, u32x4* tile, int t, int wave) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        const int idx = t + i * NT, row = idx >> 3;
+        const int logical = (idx & 7) ^ ((row >> 1) & 7);
+        tg_glds16(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
+    }
+}
+
 // XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup b to XCD b % 8 (observed, used for speed
 // only: any mapping is correct).  Each XCD owns a contiguous band of the `major` tile axis and walks it in
 // 8 x 8 supertiles, so the workgroups resident on one XCD share 8 + 8 operand panels through that XCD's
@@ -199,7 +212,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             sh[j] = a.rshift[c];
             sc[j] = a.rscale[c];
         }
-        breg.load(a.St, (size_t)k0, bpitch, (size_t)step, t);
+        if (!TG_GLDS) breg.load(a.St, (size_t)k0, bpitch, (size_t)step, t);
     };
     auto store_stage = [&](u32x4* st) {
 #pragma unroll
@@ -215,10 +228,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             const int row = 4 * quad + i;
             st[row * 8 + tg_swz(row, slot)] = (PR::NP == 2 && slot >= 4) ? lo : hi;
         }
-        breg.store(st + GE::A_CHUNKS, t);
+        if (!TG_GLDS) breg.store(st + GE::A_CHUNKS, t);
     };
 
     if (s_begin < s_end) {
+        if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)s_begin, lds + GE::A_CHUNKS, t, wave);
         load_stage(s_begin);
         store_stage(lds);
         __syncthreads();
@@ -226,7 +240,10 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s - s_begin + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < s_end;
-            if (more) load_stage(s + 1);            // global loads in flight under the MFMAs
+            if (more) {                             // global loads / LDS-DMA in flight under the MFMAs
+                if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
+                load_stage(s + 1);
+            }
             tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
             if (more) store_stage(nxt);
             __syncthreads();
@@ -525,9 +542,24 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
         for (int j = 0; j < GE::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     {
+        const size_t pitch = (size_t)nsteps * 128;
+#if TG_GLDS
+        tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, 0, lds, t, wave);
+        tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, 0, lds + GE::A_CHUNKS, t, wave);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
+            u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
+            if ((s + 1) < nsteps) {                 // DMA of the next step lands while the matrix cores run
+                tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, (size_t)(s + 1), nxt, t, wave);
+                tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
+            }
+            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
+            __syncthreads();                        // drains the DMA (vmcnt) and releases `cur` for the step after next
+        }
+#else
         TgKTile<GE::TM, GE::NT> ra;
         TgKTile<GE::TN, GE::NT> rb;
-        const size_t pitch = (size_t)nsteps * 128;
         ra.load(a.dG, (size_t)v0, pitch, 0, t);
         rb.load(a.Sk, (size_t)c0, pitch, 0, t);
         ra.store(lds, t);
@@ -545,6 +577,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
             if (more) { ra.store(nxt, t); rb.store(nxt + GE::A_CHUNKS, t); }
             __syncthreads();
         }
+#endif
     }
 
     // ---------------- epilogue ----------------
