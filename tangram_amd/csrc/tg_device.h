@@ -25,6 +25,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define blockDim (hipsim::M().blockDim)
 #define gridDim (hipsim::M().gridDim)
 #define TG_LDS_DECL unsigned char* tg_lds = hipsim::M().lds
+#define TG_SCHED_FENCE() ((void)0)
 #define __syncthreads() hipsim::block_barrier()
 TG_DEV float tg_exp(float x) { return expf(x); }
 TG_DEV float tg_log(float x) { return logf(x); }
@@ -62,6 +63,8 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
 // all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned
 // (cdna_hip_programming.md Guideline 17; a second __shared__ object de-pipelines, section 5 trap 4a)
 #define TG_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char tg_lds[]
+// pins the instruction order at this point (the machine scheduler otherwise sinks ds_reads next to their first use)
+#define TG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
 TG_DEV float tg_exp(float x) { return __expf(x); }

@@ -55,32 +55,49 @@ struct TgGeo {
 typedef TgGeo<128, 128, 2, 2> TgGeoSmall;
 typedef TgGeo<256, 256, 2, 4> TgGeoLarge;
 
-template <class PR, class GE>
+// One contraction step of the workgroup tile: software-pipelined over (k-chunk group q) x (blocks of GA A-fragments):
+// the ds_read_b128 of the NEXT block are issued before the MFMAs of the current one, so that the LDS latency is
+// covered by matrix work inside the wave (the compiler then waits with a partial lgkmcnt instead of lgkmcnt(0)).
+template <class PR, class GE, int GA_ = 0>
 TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[GE::FM][GE::FN]) {
+    constexpr int GA = GA_ ? GA_ : ((PR::NP == 2) ? 2 : 4);   // A fragments per block (register budget)
+    constexpr int NB = GE::FM / GA;                           // blocks per k-chunk group
+    constexpr int NG = PR::KQ * NB;                           // pipeline length
     const int r = lane & 15, g = lane >> 4;
+    const u32x4* sa = st + (wm * (GE::TM / GE::WM) + r) * 8;  // this lane's first A row
+    const u32x4* sb = st + GE::A_CHUNKS + (wn * (GE::TN / GE::WN) + r) * 8;
+    const int swr = (((wm * (GE::TM / GE::WM) + r) >> 1) & 7), swb = (((wn * (GE::TN / GE::WN) + r) >> 1) & 7);
+    // rows of successive fragments differ by 16, which leaves (row >> 1) & 7 unchanged: one swizzle per lane
+    u32x4 a[2][GA][PR::NP], b[2][GE::FN][PR::NP];
+    auto load_a = [&](int buf, int q, int blk) {
 #pragma unroll
-    for (int q = 0; q < PR::KQ; ++q) {
-        u32x4 b[GE::FN][PR::NP];
+        for (int f = 0; f < GA; ++f)
 #pragma unroll
-        for (int f = 0; f < GE::FN; ++f) {
-            const int rb = wn * (GE::TN / GE::WN) + f * 16 + r;
+            for (int p = 0; p < PR::NP; ++p) a[buf][f][p] = sa[(blk * GA + f) * 128 + ((4 * (q + p) + g) ^ swr)];
+    };
+    auto load_b = [&](int buf, int q) {
 #pragma unroll
-            for (int p = 0; p < PR::NP; ++p) b[f][p] = st[GE::A_CHUNKS + rb * 8 + tg_swz(rb, 4 * (q + p) + g)];
+        for (int f = 0; f < GE::FN; ++f)
+#pragma unroll
+            for (int p = 0; p < PR::NP; ++p) b[buf][f][p] = sb[f * 128 + ((4 * (q + p) + g) ^ swb)];
+    };
+    load_b(0, 0);
+    load_a(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int q = i / NB, blk = i % NB;
+        if (i + 1 < NG) {
+            const int qn = (i + 1) / NB, bn = (i + 1) % NB;
+            if (qn != q) load_b(qn & 1, qn);
+            load_a((i + 1) & 1, qn, bn);
         }
+        TG_SCHED_FENCE();                                     // next block's LDS reads stay ahead of this block's MFMAs
 #pragma unroll
-        for (int fb = 0; fb < GE::FM; fb += 4) {
-            u32x4 a[4][PR::NP];
+        for (int fi = 0; fi < GA; ++fi)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int ra = wm * (GE::TM / GE::WM) + (fb + f) * 16 + r;
-#pragma unroll
-                for (int p = 0; p < PR::NP; ++p) a[f][p] = st[ra * 8 + tg_swz(ra, 4 * (q + p) + g)];
-            }
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-                for (int fj = 0; fj < GE::FN; ++fj) acc[fb + fi][fj] = PR::mma(a[fi], b[fj], acc[fb + fi][fj]);
-        }
+            for (int fj = 0; fj < GE::FN; ++fj)
+                acc[blk * GA + fi][fj] = PR::mma(a[i & 1][fi], b[q & 1][fj], acc[blk * GA + fi][fj]);
+        TG_SCHED_FENCE();
     }
 }
 
@@ -244,7 +261,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
                 if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
                 load_stage(s + 1);
             }
-            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
+            tg_tile_mma<PR, GE, (PR::NP == 2 ? 1 : 2)>(cur, wm, wn, lane, acc);    // the M staging registers leave room for small blocks only
             if (more) store_stage(nxt);
             __syncthreads();
         }
