@@ -65,6 +65,10 @@ typedef struct tg_config {
     int32_t tile_size;       /* 0 = choose automatically; 128 or 256 = GEMM output tile edge (tuning / tests)        */
     float lambda_g1, lambda_d, lambda_g2, lambda_r, lambda_l1, lambda_l2;
     float lambda_count, lambda_f_reg, target_count;     /* constrained mode (:426-428, :480-483) */
+    float lambda_neighborhood_g1;                       /* spatially weighted gene term (:33, :234-239); needs W, W^T */
+    float lambda_ct_islands;                            /* cell-type islands (:40, :242-248); needs N, N^T, ct_encode   */
+    int32_t n_cell_types;                               /* T: columns of ct_encode */
+    int32_t nnz_w, nnz_n;                               /* non-zeros of the two spot graphs */
     float beta1, beta2, eps;                            /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 (:373) */
 } tg_config;
 
@@ -83,6 +87,14 @@ typedef struct tg_inputs {
     const float* d_source_dev;  /* [C]     source density or NULL                 (:120) */
     const float* M0_dev;        /* [C][V]  initial logits, dense pitch V          (:150-157) */
     const float* F0_dev;        /* [C]     initial filter logits (constrained)    (:490) */
+    const float* ct_encode_dev; /* [C][T]  one-hot cell types                     (:134-136) or NULL */
+    /* spot graphs as CSR (int32 indptr [V+1], int32 indices [nnz], float data [nnz]) instead of the reference's dense
+     * V x V matrices (spatial_weights.py:5-29): W = voxel_weights (:125-127) and its transpose,
+     * N = neighborhood_filter (:130-132) and its transpose.  NULL when the term is off. */
+    const int32_t* w_indptr;  const int32_t* w_indices;  const float* w_data;
+    const int32_t* wt_indptr; const int32_t* wt_indices; const float* wt_data;
+    const int32_t* n_indptr;  const int32_t* n_indices;  const float* n_data;
+    const int32_t* nt_indptr; const int32_t* nt_indices; const float* nt_data;
 } tg_inputs;
 
 typedef struct tg_mapper tg_mapper;
@@ -132,6 +144,10 @@ int tg_mapper_result(tg_mapper* m, float* P_out_dev, float* F_out_dev);
 
 /* Replaces `adata_map.X.T @ S` (mapping_utils.py:402): Ghat_out_dev [V][K] = softmax(M)^T S (times f). */
 int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev);
+
+/* Replaces Mapper._val_loss_fn (mapping_optimizer.py:311-356), evaluated with the CURRENT logits:
+ * out4_dev = { gene score + voxel score, gene score, sparsity-weighted gene score, normalised map entropy }.   */
+int tg_mapper_validate(tg_mapper* m, float* out4_dev);
 
 /* Checkpoint access (the reference's adata_map resume is a stub, mapping_optimizer.py:151-153):
  * raw pointers to M / Adam m / Adam v inside `state` and the step counter.                          */

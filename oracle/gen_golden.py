@@ -35,6 +35,7 @@ CASES = {
     "cells_ragged": (131, 37, 53, 5, 40, "cells", dict(lambda_g1=1, lambda_d=1, lambda_g2=1)),
     "cells_spatial": (200, 40, 100, 6, 40, "spatial",
                       dict(lambda_g1=1, lambda_d=1, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17)),
+    "cells_val": (100, 24, 40, 9, 20, "cells", dict(lambda_g1=1, lambda_d=1, lambda_g2=0.5, val_each=2)),
     "constrained": (150, 40, 60, 7, 50, "constrained",
                     dict(lambda_d=1, lambda_g1=1, lambda_g2=1, lambda_count=1, lambda_f_reg=1, target_count=40)),
     "constrained_entropy": (90, 30, 50, 8, 30, "constrained",
@@ -85,6 +86,7 @@ def to_double(mapper):
 
 def run(mo, name, double):
     args, epochs, mode = build_inputs(name)
+    val_each = args.pop("val_each", None)
     cls = mo.MapperConstrained if mode == "constrained" else mo.Mapper
     mapper = cls(device="cpu", random_state=RANDOM_STATE, **args)
     if double:
@@ -99,7 +101,10 @@ def run(mo, name, double):
     mapper.M.grad = None
     if mode == "constrained":
         mapper.F.grad = None
-    res = mapper.train(num_epochs=epochs, learning_rate=0.1, print_each=None)
+    if val_each is not None:
+        res = mapper.train(num_epochs=epochs, learning_rate=0.1, print_each=None, val_each=val_each)
+    else:
+        res = mapper.train(num_epochs=epochs, learning_rate=0.1, print_each=None)
     out = dict(M0=M0, dM0=dM0, P=res[0])
     if mode == "constrained":
         out.update(F0=F0, dF0=dF0, F_out=res[1])
@@ -116,6 +121,9 @@ def run(mo, name, double):
         hist = res[1]
         for k in ["total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg"]:
             out["hist_" + k] = np.array([float(x) for x in hist[k]], dtype=np.float64)
+        if val_each is not None:
+            for k in ["val_total_loss", "val_gene_sim", "val_sp_sparsity_weighted_sim", "val_entropy"]:
+                out["hist_" + k] = np.array([float(x) for x in hist[k]], dtype=np.float64)
         out["Ghat"] = res[0].astype(np.float64).T @ args["S"].astype(np.float64)
     return out
 

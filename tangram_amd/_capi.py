@@ -27,7 +27,9 @@ class TgConfig(ct.Structure):
                  "has_density", "has_d_source", "fwd_splits", "tile_size")] + \
                [(n, ct.c_float) for n in
                 ("lambda_g1", "lambda_d", "lambda_g2", "lambda_r", "lambda_l1", "lambda_l2",
-                 "lambda_count", "lambda_f_reg", "target_count", "beta1", "beta2", "eps")]
+                 "lambda_count", "lambda_f_reg", "target_count", "lambda_neighborhood_g1", "lambda_ct_islands")] + \
+               [(n, ct.c_int32) for n in ("n_cell_types", "nnz_w", "nnz_n")] + \
+               [(n, ct.c_float) for n in ("beta1", "beta2", "eps")]
 
 
 class TgSizes(ct.Structure):
@@ -36,7 +38,9 @@ class TgSizes(ct.Structure):
 
 
 class TgInputs(ct.Structure):
-    _fields_ = [(n, ct.c_void_p) for n in ("S_dev", "G_dev", "d_dev", "d_source_dev", "M0_dev", "F0_dev")]
+    _fields_ = [(n, ct.c_void_p) for n in ("S_dev", "G_dev", "d_dev", "d_source_dev", "M0_dev", "F0_dev", "ct_encode_dev",
+                                           "w_indptr", "w_indices", "w_data", "wt_indptr", "wt_indices", "wt_data",
+                                           "n_indptr", "n_indices", "n_data", "nt_indptr", "nt_indices", "nt_data")]
 
 
 _lib = None
@@ -59,19 +63,21 @@ def _declare(lib):
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
     lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
+    lib.tg_mapper_validate.argtypes = [vp, vp]
     lib.tg_mapper_profile.argtypes = [vp, i32]
     lib.tg_mapper_profile_read.argtypes = [vp, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_float), ct.POINTER(i32), i32,
                                            ct.POINTER(i32)]
     for name in ("tg_query_sizes", "tg_mapper_create", "tg_mapper_step", "tg_mapper_phase",
                  "tg_mapper_exchange_buffer", "tg_mapper_result", "tg_mapper_project", "tg_mapper_state",
-                 "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read"):
+                 "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read", "tg_mapper_validate"):
         getattr(lib, name).restype = i32
     return lib
 
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
            "tg_mapper_step", "tg_mapper_phase", "tg_mapper_exchange_buffer", "tg_mapper_result",
-           "tg_mapper_project", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read"]
+           "tg_mapper_project", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read",
+           "tg_mapper_validate"]
 
 
 def lib():

@@ -56,7 +56,9 @@ static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
     size_t o_Sk, o_St, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
-        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X, total;
+        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X,
+        o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[4][3], total;
+    int T_ct, Tp, has_nb, has_ct;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
@@ -89,7 +91,17 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     if (cfg->tile_size != 0 && cfg->tile_size != 128 && cfg->tile_size != 256) return tg_fail(TG_ERR_INVALID, "tile_size must be 0, 128 or 256");
     // large geometry (256 x 256 tiles, one 512-thread workgroup per CU) once every tile axis is long enough to fill the chip
     L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 1024) ? 256 : 128);
-    L->Kp = (int)rup((size_t)L->K + 1, L->T);
+    L->has_nb = cfg->lambda_neighborhood_g1 > 0.f;
+    L->has_ct = cfg->lambda_ct_islands > 0.f;
+    if ((L->has_nb || L->has_ct) && cfg->mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_INVALID, "spatial terms exist only in Mapper (mapping_utils.py:366-375 ignores them in constrained mode)");
+    if ((L->has_nb || L->has_ct) && cfg->n_spots_total > 0 && cfg->n_spots_total != cfg->n_spots)
+        return tg_fail(TG_ERR_UNSUPPORTED, "spatial terms need the whole spot graph on one GPU (no halo exchange yet)");
+    if (L->has_ct && cfg->n_cell_types < 1) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs n_cell_types >= 1");
+    if (L->has_nb && cfg->nnz_w < 1) return tg_fail(TG_ERR_INVALID, "lambda_neighborhood_g1 > 0 needs the voxel_weights graph");
+    if (L->has_ct && cfg->nnz_n < 1) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs the neighborhood_filter graph");
+    L->T_ct = L->has_ct ? cfg->n_cell_types : 0;
+    L->Tp = (int)rup((size_t)(L->T_ct > 0 ? L->T_ct : 1), 4);
+    L->Kp = (int)rup((size_t)L->K + 1 + L->T_ct, L->T);
     L->Vp = (int)rup(L->V, 64);
     L->Vr = (int)rup(L->V, L->T);
     L->Cp = (int)rup(L->C, 64);
@@ -129,6 +141,29 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_scal = take(64 * 4);
     L->o_fsum = take(64 * 4);
     L->o_X = take((size_t)L->C * L->Vp * 4);
+    L->o_gfrac = take((size_t)L->Kp * 4);
+    L->o_rowent = take((size_t)L->Cp * 4);
+    if (L->has_nb || L->has_ct) L->o_extra = take((size_t)L->Vr * L->Kp * 4);
+    if (L->has_nb) {
+        L->o_WG = take((size_t)L->Vr * L->Kp * 4);
+        L->o_Y = take((size_t)L->Vr * L->Kp * 4);
+        L->o_nbpart = take((size_t)L->nrb * 2 * L->Kp * 4);
+        L->o_nbstat = take((size_t)2 * L->Kp * 4);
+        L->o_wgn2 = take((size_t)2 * L->Kp * 4);
+        L->o_nbcoef = take((size_t)2 * L->Kp * 4);
+    }
+    if (L->has_ct) {
+        L->o_ctmask = take((size_t)L->Vr * L->Tp * 4);
+        L->o_ctpart = take((size_t)L->Vr * 4);
+    }
+    for (int gph = 0; gph < 4; ++gph) {           // 0: W, 1: W^T, 2: N, 3: N^T
+        const bool on = gph < 2 ? L->has_nb : L->has_ct;
+        const size_t nnz = gph < 2 ? (size_t)cfg->nnz_w : (size_t)cfg->nnz_n;
+        if (!on) continue;
+        L->o_csr[gph][0] = take((size_t)(L->V + 1) * 4);
+        L->o_csr[gph][1] = take(nnz * 4);
+        L->o_csr[gph][2] = take(nnz * 4);
+    }
     L->total = off;
     size_t so = 0;
     auto stake = [&](size_t bytes) { size_t o = so; so += rup(bytes, 256); return o; };
@@ -204,6 +239,7 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     TgPrepSArgs a;
     a.S = in->S_dev; a.C = L.C; a.K = L.K;
     a.aug = m->cfg.has_d_source ? in->d_source_dev : nullptr;
+    a.ct = L.has_ct ? in->ct_encode_dev : nullptr; a.T = L.T_ct;
     a.Sk = m->ws + L.o_Sk; a.Cr = L.Cr; a.Kp = L.Kp;
     a.St = m->ws + L.o_St; a.Cp = L.Cp;
     const size_t n1 = (size_t)L.Cr * (L.Kp / PR::CH), n2 = (size_t)L.Kp * (L.Cp / PR::CH);
@@ -233,6 +269,82 @@ static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize,
     TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
     tg_prof_mark(m, "tg_merge_stats");
     TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+static TgCsr tg_csr(const tg_mapper* m, int gph) {
+    const TgLayout& L = m->L;
+    TgCsr c;
+    c.indptr = (const int*)(m->ws + L.o_csr[gph][0]);
+    c.indices = (const int*)(m->ws + L.o_csr[gph][1]);
+    c.data = (const float*)(m->ws + L.o_csr[gph][2]);
+    return c;
+}
+
+// spatial terms, set-up: library-owned copies of the CSR graphs, W G and |W G_k|^2 (constant: :236 recomputes it every iteration)
+static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
+    const TgLayout& L = m->L;
+    const void* src[4][3] = {{in->w_indptr, in->w_indices, in->w_data}, {in->wt_indptr, in->wt_indices, in->wt_data},
+                             {in->n_indptr, in->n_indices, in->n_data}, {in->nt_indptr, in->nt_indices, in->nt_data}};
+    for (int gph = 0; gph < 4; ++gph) {
+        const bool on = gph < 2 ? L.has_nb : L.has_ct;
+        if (!on) continue;
+        const size_t nnz = gph < 2 ? (size_t)m->cfg.nnz_w : (size_t)m->cfg.nnz_n;
+        for (int j = 0; j < 3; ++j)
+            if (!src[gph][j]) return tg_fail(TG_ERR_INVALID, "a spatial term is enabled but its CSR graph (or the transpose) is NULL");
+        TG_CK(tg_memcpy(m->ws + L.o_csr[gph][0], src[gph][0], (size_t)(L.V + 1) * 4, m->stream));
+        TG_CK(tg_memcpy(m->ws + L.o_csr[gph][1], src[gph][1], nnz * 4, m->stream));
+        TG_CK(tg_memcpy(m->ws + L.o_csr[gph][2], src[gph][2], nnz * 4, m->stream));
+    }
+    if (L.has_ct && !in->ct_encode_dev) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs ct_encode");
+    if (L.has_nb) {
+        TgSpmmArgs a;
+        a.W = tg_csr(m, 0); a.A = m->fp(L.o_Gp); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
+        a.Y = m->fp(L.o_WG); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
+        const int nrb = (L.V + TG_RB - 1) / TG_RB;
+        TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_WG), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
+        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_wgn2));
+        TG_CK(tg_check_launch());
+    }
+    return TG_OK;
+}
+
+// spatial terms, per iteration, part 1 (before tg_loss_finalize): W Ghat and its per-gene statistics; ct-islands mask
+static int tg_launch_spatial_stats(tg_mapper* m) {
+    const TgLayout& L = m->L;
+    if (L.has_nb) {
+        TgSpmmArgs a;
+        a.W = tg_csr(m, 0); a.A = m->fp(L.o_Ghat); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
+        a.Y = m->fp(L.o_Y); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
+        const int nrb = (L.V + TG_RB - 1) / TG_RB;
+        TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_Y), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
+        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_nbstat));
+        tg_prof_mark(m, "tg_spatial_nb_stats");
+    }
+    if (L.has_ct) {
+        TgCtArgs c;
+        c.N = tg_csr(m, 2); c.Ghat = m->fp(L.o_Ghat); c.mask = m->fp(L.o_ctmask); c.ctpart = m->fp(L.o_ctpart);
+        c.extra = m->fp(L.o_extra); c.V = L.V; c.Kp = L.Kp; c.K = L.K; c.T = L.T_ct; c.Tp = L.Tp; c.lambda_ct = m->cfg.lambda_ct_islands;
+        TG_LAUNCH(tg_ct_mask, L.V, 1, 64, 0, m->stream, c);
+        c.N = tg_csr(m, 3);
+        TG_LAUNCH(tg_ct_grad, L.V, 1, 64, 0, m->stream, c);
+        tg_prof_mark(m, "tg_spatial_ct");
+    }
+    return TG_OK;
+}
+
+// part 2 (after tg_loss_finalize): extra[:, :K] = W^T (nbcoef0 * WG + nbcoef1 * W Ghat)
+static int tg_launch_spatial_grad(tg_mapper* m) {
+    const TgLayout& L = m->L;
+    if (L.has_nb) {
+        TgSpmmArgs a;
+        a.W = tg_csr(m, 1); a.A = m->fp(L.o_WG); a.B = m->fp(L.o_Y); a.ca = m->fp(L.o_nbcoef); a.cb = m->fp(L.o_nbcoef) + L.Kp;
+        a.Y = m->fp(L.o_extra); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
+        tg_prof_mark(m, "tg_spatial_nb_grad");
+    }
     return TG_OK;
 }
 
@@ -290,10 +402,14 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     }
     if (rc) return bail(rc);
     // padded G, |G_v|^2, |G_k|^2 partials (reuse genepart as scratch)
+    // (genepart [nrb][2][Kp] doubles as scratch: first half |G|^2 partials, second half non-zero counts)
     TG_LAUNCH(tg_prep_g, L.nrb, 1, 256, 4 * TG_RB * 4, m->stream, in->G_dev, L.V, L.K, L.Vr, L.Kp, m->fp(L.o_Gp),
-              m->fp(L.o_vnorm2), m->fp(L.o_genepart));
+              m->fp(L.o_vnorm2), m->fp(L.o_genepart), m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp);
     TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_genepart), L.nrb, L.Kp,
-              m->fp(L.o_gnorm2));
+              m->fp(L.o_gnorm2), 1.f);
+    TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream,
+              (const float*)(m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp), L.nrb, L.Kp, m->fp(L.o_gfrac), 1.f / (float)L.V);
+    if ((L.has_nb || L.has_ct) && (rc = tg_setup_spatial(m, in))) return bail(rc);
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
     if (tg_check_launch()) return bail(tg_fail(TG_ERR_HIP, "set-up kernel launch failed"));
@@ -329,12 +445,12 @@ static int tg_launch_forward(tg_mapper* m) {
     return TG_OK;
 }
 
-static int tg_launch_ghat_stats(tg_mapper* m) {
+static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
     const TgLayout& L = m->L;
     TgGhatReduceArgs a;
     a.Gpart = m->fp(L.o_Gpart); a.nsplit = L.nsplit; a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
     a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat);
-    a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = (m->cfg.lambda_g2 != 0.f);
+    a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = force_vox || (m->cfg.lambda_g2 != 0.f);
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
     TG_LAUNCH(tg_ghat_reduce, nrb, 1, 256, 4 * TG_RB * 2 * 4, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
@@ -356,12 +472,20 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     f.rho_scale = m->cfg.has_d_source ? 1.f : 1.f / (float)L.C;
     f.fsum_dev = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fsum) : nullptr;
     f.K = L.K; f.Kp = L.Kp; f.V = L.V; f.Vr = L.Vr; f.V_total = L.Vtot; f.has_density = m->cfg.has_density;
+    f.nbstat = L.has_nb ? m->fp(L.o_nbstat) : nullptr; f.wgnorm2 = L.has_nb ? m->fp(L.o_wgn2) : nullptr;
+    f.nbcoef = L.has_nb ? m->fp(L.o_nbcoef) : nullptr;
+    f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.V;
+    f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
+    int rcs = tg_launch_spatial_stats(m);
+    if (rcs) return rcs;
     TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 64, m->stream, f);
     tg_prof_mark(m, "tg_loss_finalize");
+    if ((rcs = tg_launch_spatial_grad(m))) return rcs;
     TgEmitArgs e;
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
-    e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K;
+    e.extra = (L.has_nb || L.has_ct) ? m->fp(L.o_extra) : nullptr;
+    e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
     TG_LAUNCH((tg_dghat_emit<PR>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
     tg_prof_mark(m, "tg_dghat_emit");
     return TG_OK;
@@ -562,6 +686,31 @@ extern "C" int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev) {
     if (rc) return rc;
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     TG_CK(tg_memcpy2d(Ghat_out_dev, (size_t)L.K * 4, m->ws + L.o_Ghat, (size_t)L.Kp * 4, (size_t)L.K * 4, L.V, m->stream));
+    return TG_OK;
+}
+
+extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    if (!out4_dev) return tg_fail(TG_ERR_INVALID, "out is NULL");
+    const TgLayout& L = m->L;
+    if (L.Vtot != L.V) return tg_fail(TG_ERR_UNSUPPORTED, "validation metrics are not available on a spot shard");
+    if (m->cfg.mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_INVALID, "MapperConstrained has no validation loss (mapping_optimizer.py:589)");
+    int rc;
+    switch (m->cfg.precision) {
+        case TG_PREC_F32: rc = tg_launch_forward<PrecF32>(m); break;
+        case TG_PREC_BF16: rc = tg_launch_forward<PrecBF16>(m); break;
+        default: rc = tg_launch_forward<PrecBF16x3>(m); break;
+    }
+    if (rc) return rc;
+    if ((rc = tg_launch_ghat_stats(m, true))) return rc;
+    TG_LAUNCH(tg_row_entropy, L.C, 1, 256, 64, m->stream, (const float*)(m->st + L.s_M), (const float*)m->fp(L.o_rshift),
+              (const float*)m->fp(L.o_rinvz), L.V, L.Vp, m->fp(L.o_rowent));
+    TgValArgs a;
+    a.genestat = m->fp(L.o_genestat); a.gnorm2 = m->fp(L.o_gnorm2); a.gfrac = m->fp(L.o_gfrac);
+    a.voxstat = m->fp(L.o_voxstat); a.vnorm2 = m->fp(L.o_vnorm2); a.rowent = m->fp(L.o_rowent);
+    a.out = out4_dev; a.K = L.K; a.Kp = L.Kp; a.V = L.V; a.Vr = L.Vr; a.C = L.C;
+    TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);
+    TG_CK(tg_check_launch());
     return TG_OK;
 }
 

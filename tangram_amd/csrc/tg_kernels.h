@@ -402,6 +402,12 @@ struct TgFinalizeArgs {
     float rho_scale;           // 1/C for a uniform source, 1 for d_source (rho_v = colsum_v * rho_scale)
     const float* fsum_dev;     // constrained mode: rho_v = colsum_v / sum_c f_c  (mapping_optimizer.py:512-513); else null
     int K, Kp, V, Vr, V_total, has_density;
+    // spatial refinement terms (mapping_optimizer.py:234-248)
+    const float* nbstat;       // [2][Kp] (dot(W Ghat, W G), |W Ghat|^2) per gene, or null
+    const float* wgnorm2;      // [Kp] |W G|^2 per gene
+    float* nbcoef;             // [2][Kp] -> d(loss)/d(W Ghat) = nbcoef0 * WG + nbcoef1 * WGhat
+    const float* ctpart; int n_ctpart;   // per-spot sums of relu(D) (ct islands), or null
+    float lambda_nb, lambda_ct; int T;
 };
 
 TG_DEV float tg_block_sum_1024(float x, float* red) {
@@ -438,6 +444,28 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
         a.coef[a.Kp + k] = be;
     }
     const float gv = tg_block_sum_1024(cs, red) / (float)a.K;
+    float nbs = 0.f;
+    if (a.nbstat) {
+        for (int k = t; k < a.Kp; k += 1024) {
+            float al = 0.f, be = 0.f;
+            if (k < a.K) {
+                const float dot = a.nbstat[k];
+                const float na = tg_fmax(sqrtf(a.nbstat[a.Kp + k]), TG_COS_EPS);
+                const float nb = tg_fmax(sqrtf(a.wgnorm2[k]), TG_COS_EPS);
+                const float c = dot / (na * nb);
+                nbs += c;
+                const float w = a.lambda_nb / (float)a.K;
+                al = -w / (na * nb);
+                be = w * c / (na * na);
+            }
+            a.nbcoef[k] = al;
+            a.nbcoef[a.Kp + k] = be;
+        }
+    }
+    const float nbv = tg_block_sum_1024(nbs, red) / (float)a.K;
+    float cts = 0.f;
+    if (a.ctpart) for (int i = t; i < a.n_ctpart; i += 1024) cts += a.ctpart[i];
+    const float isl = tg_block_sum_1024(cts, red) / ((float)a.V * (float)(a.T > 0 ? a.T : 1));
 
     float vs = 0.f, kl = 0.f;
     const float rho_scale = a.fsum_dev ? 1.f / a.fsum_dev[0] : a.rho_scale;
@@ -478,6 +506,8 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
         a.hist[TGH_MAIN] = gv;
         a.hist[TGH_VG] = (a.lambda_g2 != 0.f) ? vg : nanv;        // reference: 0*x/0 = nan (:209)
         a.hist[TGH_KL] = a.has_density ? klsum : nanv;
+        if (a.nbstat) { a.hist[TGH_NB] = nbv; a.hist[TGH_TOTAL] -= a.lambda_nb * nbv; }
+        if (a.ctpart) { a.hist[TGH_CT] = isl; a.hist[TGH_TOTAL] += a.lambda_ct * isl; }
     }
 }
 
@@ -486,8 +516,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
 // ----------------------------------------------------------------------------------------------
 struct TgEmitArgs {
     const float* Ghat; const float* G; const float* coef; const float* vcoef;
+    const float* extra;        // [Vr][Kp] additional d(loss)/dGhat (spatial terms; also feeds the augmentation columns) or null
     unsigned char* dG;
-    int V, Vr, Kp, K;
+    int V, Vr, Kp, K, n_aug;   // columns K+1 .. K+n_aug-1 carry the cell-type gradient
 };
 
 template <class PR>
@@ -506,8 +537,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
         for (int e = 0; e < PR::CH; ++e) {
             const size_t off = (size_t)v * a.Kp + k + e;
             const float gh = a.Ghat[off], g = a.G[off];
-            const float val = (a.coef[k + e] + va) * g + (a.coef[a.Kp + k + e] + vb) * gh;
-            x[e] = (k + e < a.K) ? val : 0.f;
+            float val = (a.coef[k + e] + va) * g + (a.coef[a.Kp + k + e] + vb) * gh;
+            const float ex = a.extra ? a.extra[off] : 0.f;
+            if (k + e < a.K) val += ex;
+            else val = (k + e > a.K && k + e < a.K + a.n_aug) ? ex : 0.f;
+            x[e] = val;
         }
         tg_store_operand_chunk<PR>(a.dG + (size_t)v * pitch, k / PR::BKE, (k % PR::BKE) / PR::CH, x);
     }
@@ -705,6 +739,77 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
                 a.part[((size_t)vt * 2 + 1) * a.C + c] = sum;
             }
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Spatial refinement terms (mapping_optimizer.py:234-248) on V x K matrices with CSR spot graphs (~6 nnz / row)
+// instead of the reference's dense V x V products (spatial_weights.py:5-29).
+// ----------------------------------------------------------------------------------------------
+struct TgCsr { const int* indptr; const int* indices; const float* data; };
+
+// Y[v][k] (op)= sum_j W[v][j] * src[j][k], k in [k_begin, k_end); src = A, or ca[k]*A + cb[k]*B when ca != null.
+// One workgroup per spot row, threads along genes (coalesced).
+struct TgSpmmArgs {
+    TgCsr W; const float* A; const float* B; const float* ca; const float* cb;
+    float* Y; int V, Kp, k_begin, k_end;
+};
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_spmm(TgSpmmArgs a) {
+    const int v = blockIdx.x;
+    const int b = a.W.indptr[v], e = a.W.indptr[v + 1];
+    for (int k = a.k_begin + threadIdx.x; k < a.k_end; k += 256) {
+        float s = 0.f;
+        for (int i = b; i < e; ++i) {
+            const size_t off = (size_t)a.W.indices[i] * a.Kp + k;
+            const float x = a.ca ? (a.ca[k] * a.A[off] + a.cb[k] * a.B[off]) : a.A[off];
+            s += a.W.data[i] * x;
+        }
+        a.Y[(size_t)v * a.Kp + k] = s;
+    }
+}
+
+// per-gene partial sums over a block of TG_RB spots: (sum A*B, sum A*A)  [second stage: tg_gene_reduce]
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_colstats(const float* A, const float* B, int V, int Kp, float* part /*[nrb][2][Kp]*/) {
+    const int rb = blockIdx.x, vbeg = rb * TG_RB;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        float d = 0.f, n = 0.f;
+        for (int i = 0; i < TG_RB; ++i) {
+            const int v = vbeg + i;
+            if (v < V) { const float x = A[(size_t)v * Kp + k]; d += x * B[(size_t)v * Kp + k]; n += x * x; }
+        }
+        part[((size_t)rb * 2 + 0) * Kp + k] = d;
+        part[((size_t)rb * 2 + 1) * Kp + k] = n;
+    }
+}
+
+// cell-type islands (:242-248): ct = Ghat[:, K+1 : K+1+T]; D = ct - N ct; penalty = mean(max(D, 0));
+// mask = 1[D > 0] / (V T)   (the reference's binary torch.max splits exact ties 0.5/0.5; ties have measure zero)
+struct TgCtArgs {
+    TgCsr N; const float* Ghat; float* mask /*[Vr][Tp]*/; float* ctpart /*[V]*/; float* extra;
+    int V, Kp, K, T, Tp; float lambda_ct;
+};
+TG_KERNEL void TG_LAUNCH_BOUNDS(64) tg_ct_mask(TgCtArgs a) {
+    const int v = blockIdx.x, b = a.N.indptr[v], e = a.N.indptr[v + 1];
+    float part = 0.f;
+    for (int t = threadIdx.x; t < a.T; t += 64) {
+        const int col = a.K + 1 + t;
+        float s = 0.f;
+        for (int i = b; i < e; ++i) s += a.N.data[i] * a.Ghat[(size_t)a.N.indices[i] * a.Kp + col];
+        const float D = a.Ghat[(size_t)v * a.Kp + col] - s;
+        a.mask[(size_t)v * a.Tp + t] = (D > 0.f) ? 1.f / ((float)a.V * (float)a.T) : 0.f;
+        part += (D > 0.f) ? D : 0.f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += tg_shfl_xor(part, m);
+    if (threadIdx.x == 0) a.ctpart[v] = part;
+}
+// d(penalty)/d(ct) = mask - N^T mask  -> augmentation columns of the extra gradient (a.N holds N^T here)
+TG_KERNEL void TG_LAUNCH_BOUNDS(64) tg_ct_grad(TgCtArgs a) {
+    const int v = blockIdx.x, b = a.N.indptr[v], e = a.N.indptr[v + 1];
+    for (int t = threadIdx.x; t < a.T; t += 64) {
+        float s = 0.f;
+        for (int i = b; i < e; ++i) s += a.N.data[i] * a.mask[(size_t)a.N.indices[i] * a.Tp + t];
+        a.extra[(size_t)v * a.Kp + a.K + 1 + t] = a.lambda_ct * (a.mask[(size_t)v * a.Tp + t] - s);
     }
 }
 
@@ -969,11 +1074,67 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_softmax_out(const float* M, const float*
 }
 
 // ----------------------------------------------------------------------------------------------
+// Validation metrics of Mapper._val_loss_fn (mapping_optimizer.py:311-356; evaluated on the TRAINING split like the
+// reference does, :321-322): gene score, voxel score, sparsity-weighted gene score, normalised row entropy.
+// ----------------------------------------------------------------------------------------------
+// one block per cell: rowent[c] = -sum_v P log P   (:333)
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_row_entropy(const float* M, const float* rshift, const float* rinvz, int V, int Vp,
+                                                    float* rowent) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float sh = rshift[c], iz = rinvz[c], liz = tg_log(iz);
+    float s = 0.f;
+    for (int v = t; v < V; v += 256) {
+        const float z = M[(size_t)c * Vp + v] - sh;
+        s += tg_exp(z) * iz * (z + liz);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += tg_shfl_xor(s, m);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (t == 0) rowent[c] = -(red[0] + red[1] + red[2] + red[3]);
+}
+
+struct TgValArgs {
+    const float* genestat; const float* gnorm2; const float* gfrac;     // [2][Kp], [Kp], [Kp] (fraction of non-zero spots per gene)
+    const float* voxstat; const float* vnorm2; const float* rowent;
+    float* out;                                                          // [4]: gv + vg, gv, sparsity-weighted gv, entropy
+    int K, Kp, V, Vr, C;
+};
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_val_finalize(TgValArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;
+    const int t = threadIdx.x;
+    float cs = 0.f, ws = 0.f, wn = 0.f;
+    for (int k = t; k < a.K; k += 1024) {
+        const float na = tg_fmax(sqrtf(a.genestat[a.Kp + k]), TG_COS_EPS), nb = tg_fmax(sqrtf(a.gnorm2[k]), TG_COS_EPS);
+        const float c = a.genestat[k] / (na * nb);
+        cs += c;
+        ws += c * a.gfrac[k];
+        wn += a.gfrac[k];
+    }
+    const float gv = tg_block_sum_1024(cs, red) / (float)a.K;
+    const float wsum = tg_block_sum_1024(ws, red), wnorm = tg_block_sum_1024(wn, red);
+    float vs = 0.f;
+    for (int v = t; v < a.V; v += 1024) {
+        const float na = tg_fmax(sqrtf(a.voxstat[a.Vr + v]), TG_COS_EPS), nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
+        vs += a.voxstat[v] / (na * nb);
+    }
+    const float vg = tg_block_sum_1024(vs, red) / (float)a.V;
+    float es = 0.f;
+    for (int c = t; c < a.C; c += 1024) es += a.rowent[c];
+    const float ent = tg_block_sum_1024(es, red) / ((float)a.C * logf((float)a.V));
+    if (t == 0) { a.out[0] = gv + vg; a.out[1] = gv; a.out[2] = wsum / wnorm; a.out[3] = ent; }
+}
+
+// ----------------------------------------------------------------------------------------------
 // set-up kernels: operand images of S and the padded fp32 copy of G
 // ----------------------------------------------------------------------------------------------
 struct TgPrepSArgs {
     const float* S; int C, K;           // caller's [C][K]
-    const float* aug;                   // [C] values of the augmentation column (null => 1)
+    const float* aug;                   // [C] values of the augmentation column K (null => 1)
+    const float* ct; int T;             // [C][T] cell-type encoding -> columns K+1 .. K+T (ct-islands term), or null
     unsigned char* Sk; int Cr, Kp;      // [Cr][Kp/BKE][128 B]   (contraction over genes)
     unsigned char* St; int Cp;          // [Kp][Cp/BKE][128 B]   (contraction over cells)
 };
@@ -981,6 +1142,7 @@ TG_DEV float tg_s_aug(const TgPrepSArgs& a, int c, int k) {
     if (c >= a.C) return 0.f;
     if (k < a.K) return a.S[(size_t)c * a.K + k];
     if (k == a.K) return a.aug ? a.aug[c] : 1.f;
+    if (a.ct && k - a.K - 1 < a.T) return a.ct[(size_t)c * a.T + (k - a.K - 1)];
     return 0.f;
 }
 template <class PR>
@@ -1010,7 +1172,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_st(TgPrepSArgs a) {
 
 // Gp = zero-padded copy of G; vnorm2[v] = sum_k G^2; gnormpart[rb][k] = partial sum_v G^2
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_g(const float* G, int V, int K, int Vr, int Kp, float* Gp, float* vnorm2,
-                                               float* gnormpart /*[nrb][Kp]*/) {
+                                               float* gnormpart /*[nrb][Kp]*/, float* gnnzpart /*[nrb][Kp]*/) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1019,7 +1181,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_g(const float* G, int V, int K, int
 #pragma unroll
     for (int i = 0; i < TG_RB; ++i) vn[i] = 0.f;
     for (int k = t; k < Kp; k += 256) {
-        float gs = 0.f;
+        float gs = 0.f, nz = 0.f;
 #pragma unroll
         for (int i = 0; i < TG_RB; ++i) {
             const int v = vbeg + i;
@@ -1027,9 +1189,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_g(const float* G, int V, int K, int
             if (v < V && k < K) x = G[(size_t)v * K + k];
             if (v < Vr) Gp[(size_t)v * Kp + k] = x;
             gs += x * x;
+            nz += (x != 0.f) ? 1.f : 0.f;
             vn[i] += x * x;
         }
         gnormpart[(size_t)blockIdx.x * Kp + k] = gs;
+        gnnzpart[(size_t)blockIdx.x * Kp + k] = nz;
     }
 #pragma unroll
     for (int i = 0; i < TG_RB; ++i) {
@@ -1042,12 +1206,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_g(const float* G, int V, int K, int
     if (t < TG_RB && vbeg + t < Vr) vnorm2[vbeg + t] = red[t] + red[TG_RB + t] + red[2 * TG_RB + t] + red[3 * TG_RB + t];
 }
 
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_colsum_parts(const float* part, int nparts, int n, float* out) {
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_colsum_parts(const float* part, int nparts, int n, float* out, float scale) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     float s = 0.f;
     for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + k];
-    out[k] = s;
+    out[k] = s * scale;
 }
 
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fill(float* p, size_t n, float val) {

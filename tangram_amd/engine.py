@@ -10,6 +10,22 @@ import torch
 from . import _capi
 
 
+def _csr_pair(mat, n, device):
+    """(CSR of mat, CSR of mat^T) as int32/float32 device tensors; `mat` is a dense array/matrix or scipy.sparse."""
+    import scipy.sparse as sp
+    m = mat if sp.issparse(mat) else sp.csr_matrix(np.asarray(mat, dtype=np.float32))
+    m = m.tocsr().astype(np.float32)
+    if m.shape != (n, n):
+        raise ValueError(f"spot graph must be {n} x {n}, got {m.shape}")
+    out = []
+    for a in (m, m.T.tocsr()):
+        a.sort_indices()
+        out.append((torch.as_tensor(a.indptr.astype(np.int32), device=device),
+                    torch.as_tensor(a.indices.astype(np.int32), device=device),
+                    torch.as_tensor(a.data.astype(np.float32), device=device)))
+    return out[0], out[1], int(m.nnz)
+
+
 def _as_dev_f32(x, device):
     if x is None:
         return None
@@ -23,7 +39,8 @@ class HipMapperEngine:
 
     def __init__(self, S, G, M0, d=None, d_source=None, F0=None, *, mode="mapper", device="cuda:0",
                  precision="bf16x3", lambdas=None, n_spots_total=None, fwd_splits=0, tile_size=0,
-                 target_count=0.0, betas=(0.9, 0.999), eps=1e-8):
+                 target_count=0.0, betas=(0.9, 0.999), eps=1e-8,
+                 voxel_weights=None, neighborhood_filter=None, ct_encode=None):
         self.device = torch.device(device)
         if self.device.type != "cuda" and not _capi.is_emulated():
             raise RuntimeError(f"tangram_amd runs on a HIP device only (got device={device!r}); there is no CPU path")
@@ -31,7 +48,7 @@ class HipMapperEngine:
             raise ValueError(f"gemm precision must be one of {sorted(_capi.PRECISIONS)}")
         self._lib = _capi.lib()
         lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0,
-                   lambda_count=1.0, lambda_f_reg=1.0)
+                   lambda_count=1.0, lambda_f_reg=1.0, lambda_neighborhood_g1=0.0, lambda_ct_islands=0.0)
         lam.update(lambdas or {})
         S = _as_dev_f32(S, self.device)
         G = _as_dev_f32(G, self.device)
@@ -61,16 +78,37 @@ class HipMapperEngine:
         cfg.beta1, cfg.beta2, cfg.eps = float(betas[0]), float(betas[1]), float(eps)
         self.cfg = cfg
         self.precision = precision
-        sizes = _capi.TgSizes()
-        _capi.check(self._lib.tg_query_sizes(ct.byref(cfg), ct.byref(sizes)))
-        self.sizes = sizes
-        self.state = torch.empty(sizes.state_bytes, dtype=torch.uint8, device=self.device)
-        self.workspace = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
         inp = _capi.TgInputs()
         inp.S_dev, inp.G_dev, inp.M0_dev = S.data_ptr(), G.data_ptr(), M0.data_ptr()
         inp.d_dev = d.data_ptr() if d is not None else None
         inp.d_source_dev = d_source.data_ptr() if d_source is not None else None
         inp.F0_dev = F0.data_ptr() if F0 is not None else None
+        keep = []                                   # keep the CSR tensors alive until create() has copied them
+        if lam["lambda_neighborhood_g1"] > 0:
+            if voxel_weights is None:
+                raise ValueError("lambda_neighborhood_g1 > 0 needs voxel_weights")
+            w, wt, cfg.nnz_w = _csr_pair(voxel_weights, self.V, self.device)
+            keep += [w, wt]
+            inp.w_indptr, inp.w_indices, inp.w_data = (x.data_ptr() for x in w)
+            inp.wt_indptr, inp.wt_indices, inp.wt_data = (x.data_ptr() for x in wt)
+        if lam["lambda_ct_islands"] > 0:
+            if neighborhood_filter is None or ct_encode is None:
+                raise ValueError("lambda_ct_islands > 0 needs neighborhood_filter and ct_encode")
+            nn, nt, cfg.nnz_n = _csr_pair(neighborhood_filter, self.V, self.device)
+            E = _as_dev_f32(ct_encode, self.device)
+            if E.shape[0] != self.C:
+                raise ValueError("ct_encode must have one row per cell")
+            cfg.n_cell_types = int(E.shape[1])
+            keep += [nn, nt, E]
+            inp.n_indptr, inp.n_indices, inp.n_data = (x.data_ptr() for x in nn)
+            inp.nt_indptr, inp.nt_indices, inp.nt_data = (x.data_ptr() for x in nt)
+            inp.ct_encode_dev = E.data_ptr()
+        self._keepalive = keep
+        sizes = _capi.TgSizes()
+        _capi.check(self._lib.tg_query_sizes(ct.byref(cfg), ct.byref(sizes)))
+        self.sizes = sizes
+        self.state = torch.empty(sizes.state_bytes, dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
         handle = ct.c_void_p()
         _capi.check(self._lib.tg_mapper_create(ct.byref(cfg), ct.byref(inp), self.state.data_ptr(),
                                                self.workspace.data_ptr(), self._stream(), ct.byref(handle)))
@@ -130,6 +168,12 @@ class HipMapperEngine:
         Gh = torch.empty((self.V, self.K), dtype=torch.float32, device=self.device)
         _capi.check(self._lib.tg_mapper_project(self._h, Gh.data_ptr()))
         return Gh
+
+    def validate(self):
+        """(expression_sim, gv_sim, sparsity-weighted gv_sim, entropy) of the current mapping; one D2H copy."""
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.tg_mapper_validate(self._h, out.data_ptr()))
+        return [float(x) for x in out.cpu().numpy()]
 
     def logits(self):
         """Views of M / Adam m / Adam v ([C, pitch] float32, columns >= V are padding)."""

@@ -83,11 +83,13 @@ class Mapper:
     ):
         if adata_map is not None:
             raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :151-153)")
-        for name, lam in (("lambda_neighborhood_g1", lambda_neighborhood_g1), ("lambda_ct_islands", lambda_ct_islands),
-                          ("lambda_getis_ord", lambda_getis_ord), ("lambda_geary", lambda_geary),
-                          ("lambda_moran", lambda_moran)):
+        for name, lam in (("lambda_getis_ord", lambda_getis_ord), ("lambda_geary", lambda_geary), ("lambda_moran", lambda_moran)):
             if lam and lam > 0:
-                raise NotImplementedError(f"{name} > 0: the spatial refinement terms are not built yet in tangram_amd")
+                raise NotImplementedError(f"{name} > 0: the spatial autocorrelation terms are not built yet in tangram_amd")
+        if not (lambda_neighborhood_g1 and lambda_neighborhood_g1 > 0):      # reference :234: only evaluated when > 0
+            lambda_neighborhood_g1, voxel_weights = 0.0, None
+        if not (lambda_ct_islands and lambda_ct_islands > 0):                # reference :242
+            lambda_ct_islands, neighborhood_filter, ct_encode = 0.0, None, None
         self.device = torch.device(device)
         self.random_state = random_state
         S = _to_numpy_f32(S)
@@ -109,9 +111,12 @@ class Mapper:
                 np.random.seed(seed=self.random_state)
             M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)
         lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
-                       lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2)
+                       lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2,
+                       lambda_neighborhood_g1=lambda_neighborhood_g1, lambda_ct_islands=lambda_ct_islands)
         self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
-                                       mode="mapper", device=self.device, precision=gemm_precision, lambdas=lambdas)
+                                       mode="mapper", device=self.device, precision=gemm_precision, lambdas=lambdas,
+                                       voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
+                                       ct_encode=_to_numpy_f32(ct_encode))
 
     # ------------------------------------------------------------------------------------------------
     def _history_dict(self, hist):
@@ -128,28 +133,34 @@ class Mapper:
 
     def train(self, num_epochs, learning_rate=0.1, print_each=100, val_each=None):
         """Run the optimizer; returns (mapping matrix ndarray [C, V], training_history) like the reference (:358-408)."""
-        if val_each is not None:
-            raise NotImplementedError("val_each (validation loss during training) is not built yet in tangram_amd")
         if self.random_state:
             torch.manual_seed(seed=self.random_state)        # reference :371-372 (no RNG is consumed afterwards)
         if print_each:
             logging.info(f"Printing scores every {print_each} epochs.")
         eng = self._engine
         hist = eng.new_history(max(int(num_epochs), 1))
+        val_rows = []
         t = 0
         while t < num_epochs:
+            stops = [num_epochs - 1]                         # last epoch of the next chunk (inclusive)
             if print_each:
-                nxt = t if t % print_each == 0 else (t // print_each + 1) * print_each
-                n = min(nxt, num_epochs - 1) - t + 1
-            else:
-                n = num_epochs - t
+                stops.append(t if t % print_each == 0 else (t // print_each + 1) * print_each)
+            if val_each is not None:
+                stops.append(t if t % val_each == 0 else (t // val_each + 1) * val_each)
+            n = min(stops) - t + 1
             eng.step(n, learning_rate, hist, t)
             t += n
             if print_each and (t - 1) % print_each == 0:
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
+            if val_each is not None and (t - 1) % val_each == 0:
+                val_rows.append(eng.validate())              # reference :398-403: after optimizer.step() of epoch t-1
         output = eng.result().detach().cpu().numpy()         # reference :406-408
-        return output, self._history_dict(hist[:num_epochs])
+        history = self._history_dict(hist[:num_epochs])
+        for row in val_rows:
+            for k, x in zip(_VAL_KEYS, row):
+                history[k].append(x)
+        return output, history
 
     # extras -----------------------------------------------------------------------------------------
     def project_genes_device(self):

@@ -10,8 +10,8 @@ Deliberate differences from the reference, all documented in DESIGN.md:
   * a dense `adata_sc.X` works (the reference calls `.toarray()` on an ndarray at :262).
   * the per-gene training scores (:402-410) are computed from the projection P^T S evaluated on the GPU instead
     of a NumPy `adata_map.X.T @ S` on the host.
-  * the spatial refinement terms (neighbourhood, cell-type islands, Getis-Ord, Moran, Geary) raise
-    NotImplementedError instead of building dense V x V weight matrices.
+  * the neighbourhood and cell-type-island terms take the spot graph as scipy CSR (tangram_amd/spatial_weights.py)
+    instead of dense V x V matrices; Getis-Ord, Moran and Geary raise NotImplementedError.
 Extra keyword: `gemm_precision` (see tangram_amd.mapping_optimizer).
 """
 from __future__ import annotations
@@ -23,6 +23,7 @@ import pandas as pd
 import torch
 
 from . import mapping_optimizer as mo
+from . import spatial_weights as sw
 from .anndata_lite import AnnDataLite, make_result_anndata
 
 logging.getLogger().setLevel(logging.INFO)
@@ -166,14 +167,23 @@ def map_cells_to_space(
     print_each = 100 if verbose else None                                     # :312-315
 
     if mode in ["cells", "clusters"]:
-        for name, lam in (("lambda_neighborhood_g1", lambda_neighborhood_g1), ("lambda_ct_islands", lambda_ct_islands),
-                          ("lambda_getis_ord", lambda_getis_ord), ("lambda_moran", lambda_moran),
+        for name, lam in (("lambda_getis_ord", lambda_getis_ord), ("lambda_moran", lambda_moran),
                           ("lambda_geary", lambda_geary)):
             if lam and lam > 0:
-                raise NotImplementedError(f"{name} > 0 is not built yet in tangram_amd (spatial refinement terms)")
+                raise NotImplementedError(f"{name} > 0 is not built yet in tangram_amd (spatial autocorrelation terms)")
+        voxel_weights, neighborhood_filter, ct_encode = None, None, None      # :318-329
+        if lambda_neighborhood_g1 > 0:
+            voxel_weights = sw.spatial_weights(adata_sp, standardized=True, self_inclusion=True)
+        if lambda_ct_islands > 0:
+            if cluster_label not in adata_sc.obs.keys():
+                raise ValueError("cluster_label must be specified for the cell type island extension.")
+            neighborhood_filter = sw.spatial_weights(adata_sp, standardized=False, self_inclusion=False)
+            ct_encode, _ = sw.one_hot_encoding(adata_sc.obs[cluster_label])
         hyperparameters = {                                                   # :331-348
             "lambda_d": lambda_d, "lambda_g1": lambda_g1, "lambda_g2": lambda_g2, "lambda_r": lambda_r,
             "lambda_l1": lambda_l1, "lambda_l2": lambda_l2, "d_source": d_source,
+            "lambda_neighborhood_g1": lambda_neighborhood_g1, "voxel_weights": voxel_weights,
+            "lambda_ct_islands": lambda_ct_islands, "neighborhood_filter": neighborhood_filter, "ct_encode": ct_encode,
         }
         logging.info("Begin training with {} genes and {} density_prior in {} mode...".format(
             len(training_genes), d_str, mode))

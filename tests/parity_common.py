@@ -26,6 +26,7 @@ def run_case(name, device, precision, epochs=None):
     import tangram_amd.mapping_optimizer as mo
     z = load_golden(name)
     args, n_epochs, mode = build_inputs(name)
+    val_each = args.pop("val_each", None)
     if epochs is not None:
         n_epochs = min(n_epochs, epochs)
     if mode == "constrained":
@@ -33,7 +34,7 @@ def run_case(name, device, precision, epochs=None):
         P, F, hist = m.train(num_epochs=n_epochs, learning_rate=0.1, print_each=None)
     else:
         m = mo.Mapper(device=device, gemm_precision=precision, M_init=z["f32_M0"], **args)
-        P, hist = m.train(num_epochs=n_epochs, learning_rate=0.1, print_each=None)
+        P, hist = m.train(num_epochs=n_epochs, learning_rate=0.1, print_each=None, val_each=val_each)
         F = None
     Ghat = m.project_genes_device().detach().cpu().numpy()
     return dict(P=P, F=F, hist=hist, Ghat=Ghat, z=z, epochs=n_epochs, mode=mode)
@@ -46,6 +47,7 @@ def check_against_golden(res, precision, full_length):
     keys = ["main_loss", "total_loss", "kl_reg", "vg_reg", "entropy_reg"]
     if res["mode"] == "constrained":
         keys += ["count_reg", "lambda_f_reg"]
+    # (the spatial terms enter total_loss; the reference keeps no separate history for them, :378-392)
     for k in keys:
         ref = z["f64_hist_" + k][:n]
         got = np.array([float(x) for x in res["hist"][k]], dtype=np.float64)
@@ -67,5 +69,10 @@ def check_against_golden(res, precision, full_length):
             assert dF <= tol["P"], f"max|dF| {dF:.3e}"
         am = (res["P"].argmax(1) == z["f64_P"].argmax(1)).mean()
         assert am >= (0.98 if precision != "bf16" else 0.9), f"argmax agreement {am:.3f}"
+    if "f64_hist_val_gene_sim" in z.files:       # Mapper._val_loss_fn metrics (mapping_optimizer.py:311-356)
+        for k in ("val_total_loss", "val_gene_sim", "val_sp_sparsity_weighted_sim", "val_entropy"):
+            got = np.array(res["hist"][k], dtype=np.float64)
+            ref = z["f64_hist_" + k][:len(got)]
+            assert len(got) > 0 and float(np.abs(got - ref).max()) <= 10 * tol["loss"], (k, got, ref)
     np.testing.assert_allclose(res["P"].sum(axis=1), 1.0, atol=1e-5)
     assert (res["P"] >= 0).all()

@@ -109,3 +109,31 @@ def test_clusters_and_constrained_modes(sim):
     Pc, Fc, _ = oc.train(4)
     np.testing.assert_allclose(ad_map2.X, Pc, atol=1e-5)
     np.testing.assert_allclose(ad_map2.obs["F_out"].to_numpy(), Fc, atol=1e-5)
+
+
+def test_spatial_extension_terms_with_csr_graph(sim):
+    """lambda_neighborhood_g1 + lambda_ct_islands through map_cells_to_space with obsp spot graphs (CSR), against
+    the oracle fed with the dense matrices the reference would build (spatial_weights.py:5-29)."""
+    import scipy.sparse as sp
+    import tangram_amd as tg
+    ad_sc, ad_sp = _adatas(C=50, K=10, V=25)
+    W_bin = orc.grid_graph(25, standardized=False, self_inclusion=False)
+    rng = np.random.default_rng(0)
+    dist = W_bin * rng.uniform(0.5, 2.0, size=W_bin.shape).astype(np.float32)
+    ad_sp.obsp["spatial_connectivities"] = sp.csr_matrix(W_bin)
+    ad_sp.obsp["spatial_distances"] = sp.csr_matrix(dist)
+    n = 5
+    ad_map = tg.map_cells_to_space(ad_sc, ad_sp, mode="cells", cluster_label="subclass_label", device="cpu", num_epochs=n,
+                                   random_state=42, verbose=False, gemm_precision="fp32",
+                                   lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17)
+    train = ad_sc.uns["training_genes"]
+    Wd = dist / dist.sum(1, keepdims=True) + np.eye(25, dtype=np.float32)
+    lab = ad_sc.obs["subclass_label"]
+    E = np.stack([(lab == c).to_numpy().astype(np.float32) for c in lab.unique()], axis=1)
+    o = orc.OracleMapper(ad_sc[:, train].X, ad_sp[:, train].X, d=ad_sp.obs["rna_count_based_density"].to_numpy(), lambda_d=1,
+                         lambda_neighborhood_g1=0.96, voxel_weights=Wd, lambda_ct_islands=0.17,
+                         neighborhood_filter=W_bin, ct_encode=E, random_state=42)
+    Po, ho = o.train(n)
+    hist = ad_map.uns["training_history"]
+    np.testing.assert_allclose([float(x) for x in hist["total_loss"]], ho["total_loss"], atol=1e-5)
+    np.testing.assert_allclose(ad_map.X, Po, atol=1e-5)

@@ -17,6 +17,7 @@ def _load(golden_dir, name):
 
 def _make(name, z, dtype):
     args, epochs, mode = build_inputs(name)
+    args.pop("val_each", None)
     if mode == "constrained":
         m = orc.OracleMapperConstrained(M0=z["f32_M0"], F0=z["f32_F0"], dtype=dtype, **args)
     else:

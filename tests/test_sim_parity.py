@@ -28,6 +28,8 @@ def sim():
     ("cells_ragged", "bf16", 6),
     ("constrained", "fp32", 8),          # MapperConstrained: filter F, count / f_reg terms
     ("constrained_entropy", "bf16x3", 6),
+    ("cells_val", "bf16x3", 7),          # val_each: validation metrics of _val_loss_fn
+    ("cells_spatial", "fp32", 6),        # neighbourhood-weighted gene term + cell-type islands on a CSR spot graph
 ])
 def test_emulated_kernels_match_reference(sim, name, precision, epochs):
     res = pc.run_case(name, "cpu", precision, epochs=epochs)
