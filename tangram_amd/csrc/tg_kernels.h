@@ -213,6 +213,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     bool vok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) vok[i] = (vcol + i) < a.V;
+    const bool full_tile = (v0 + GE::TM) <= a.V;               // wave-uniform: interior tiles skip the per-element selects
 
     f32x4 mreg[PR::CH];
     float sh[PR::CH], sc[PR::CH];
@@ -238,7 +239,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
 #pragma unroll
             for (int j = 0; j < PR::CH; ++j) {
                 const float p = tg_exp(mreg[j][i] - sh[j]) * sc[j];
-                x[j] = vok[i] ? p : 0.f;
+                x[j] = (full_tile || vok[i]) ? p : 0.f;
             }
             u32x4 hi, lo;
             PR::cvt(x, hi, lo);
@@ -636,7 +637,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     const int g = lane >> 4, r15 = lane & 15;
     constexpr int NP = (PHASE == 1) ? (FULL ? (int)TGP1_N : 1) : 2;
     constexpr int FM = GE::FM, FN = GE::FN;
-    constexpr int EB = 2;                                      // spot quads whose global loads are issued together
+    constexpr int EB = GE::FM;                                 // spot quads whose global loads are in flight together (1 workgroup per CU: the epilogue needs its own memory-level parallelism)
     const int vbase = v0 + wm * (GE::TM / GE::WM) + 4 * g;      // + fi * 16
     float pacc[FN][NP];
 
