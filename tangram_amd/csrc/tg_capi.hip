@@ -412,6 +412,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     if ((L.has_nb || L.has_ct) && (rc = tg_setup_spatial(m, in))) return bail(rc);
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
+    TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rscale), (size_t)L.Cp, 3.0e38f);
     if (tg_check_launch()) return bail(tg_fail(TG_ERR_HIP, "set-up kernel launch failed"));
     if (cfg->mode == TG_MODE_CONSTRAINED) {
         if (tg_memcpy(m->st + L.s_F, in->F0_dev, (size_t)L.C * 4, m->stream)) return bail(tg_fail(TG_ERR_HIP, "copy of F0 failed"));
@@ -433,7 +434,7 @@ static int tg_launch_forward(tg_mapper* m) {
     const TgLayout& L = m->L;
     TgFwdArgs a;
     a.M = (const float*)(m->st + L.s_M);
-    a.rshift = m->fp(L.o_rshift); a.rscale = m->fp(L.o_rscale);
+    a.rlse2 = m->fp(L.o_rscale);
     a.St = m->ws + L.o_St;
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;

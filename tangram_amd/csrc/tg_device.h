@@ -29,6 +29,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define __syncthreads() hipsim::block_barrier()
 TG_DEV float tg_exp(float x) { return expf(x); }
 TG_DEV float tg_log(float x) { return logf(x); }
+TG_DEV float tg_exp2(float x) { return exp2f(x); }
 TG_DEV float tg_rcp(float x) { return 1.0f / x; }
 TG_DEV float tg_shfl_xor(float v, int mask) { return hipsim::shfl_idx(v, hipsim::lane_id() ^ mask); }
 TG_DEV int tg_lane() { return hipsim::lane_id(); }
@@ -69,6 +70,7 @@ typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
 TG_DEV float tg_exp(float x) { return __expf(x); }
 TG_DEV float tg_log(float x) { return __logf(x); }
+TG_DEV float tg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
 TG_DEV float tg_rcp(float x) { return __frcp_rn(x); }
 TG_DEV float tg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 TG_DEV int tg_lane() { return threadIdx.x & 63; }
@@ -101,6 +103,7 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
 TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }
 TG_DEV float tg_bf16_hi_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }
 TG_DEV float tg_fmax(float a, float b) { return a > b ? a : b; }
+#define TG_LOG2E 1.4426950408889634f
 
 // ----------------------------------------------------------------------------------------------
 // GEMM operand precision policies.

@@ -165,8 +165,8 @@ TG_HD bool tg_tilemap(const TgTileMap& m, int b, int& major, int& minor) {
 // ----------------------------------------------------------------------------------------------
 struct TgFwdArgs {
     const float* M;
-    const float* rshift;     // [Cp] per-row softmax shift (row max); padding = +3e38
-    const float* rscale;     // [Cp] per-row scale 1/Z (times the filter f_c in constrained mode); padding = 0
+    const float* rlse2;      // [Cp] per-row log2-domain log-sum-exp: (max + ln Z - ln f_c) * log2(e), so that
+                             //      P_cv f_c = exp2(M_cv * log2(e) - rlse2_c) is ONE fma + ONE v_exp_f32; padding = +3e38 (=> 0)
     const unsigned char* St; // [Kp][nsteps][128 B]
     float* Gpart;            // [nsplit][Vr][Kp]
     int C, V, Vp, Vr, Kp, Cp;
@@ -216,7 +216,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     const bool full_tile = (v0 + GE::TM) <= a.V;               // wave-uniform: interior tiles skip the per-element selects
 
     f32x4 mreg[PR::CH];
-    float sh[PR::CH], sc[PR::CH];
+    float sh[PR::CH];
     TgKTile<GE::TN, GE::NT> breg;
     const size_t bpitch = (size_t)a.nsteps * 128;
 
@@ -227,8 +227,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             const int c = cb + j;
             const int cc = c < a.C ? c : a.C - 1;
             mreg[j] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + vload);
-            sh[j] = a.rshift[c];
-            sc[j] = a.rscale[c];
+            sh[j] = a.rlse2[c];
         }
         if (!TG_GLDS) breg.load(a.St, (size_t)k0, bpitch, (size_t)step, t);
     };
@@ -238,7 +237,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             float x[PR::CH];
 #pragma unroll
             for (int j = 0; j < PR::CH; ++j) {
-                const float p = tg_exp(mreg[j][i] - sh[j]) * sc[j];
+                const float p = tg_exp2(fmaf(mreg[j][i], TG_LOG2E, -sh[j]));
                 x[j] = (full_tile || vok[i]) ? p : 0.f;
             }
             u32x4 hi, lo;
@@ -900,7 +899,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
             const float inz = 1.f / z;
             a.new_shift[c] = mx;
             a.new_invz[c] = inz;
-            a.new_scale[c] = inz;      // the constrained filter is folded in afterwards by tg_merge_stats
+            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;      // (the constrained filter is folded in by tg_merge_stats)
         }
     }
 }
@@ -1024,7 +1023,7 @@ struct TgMergeArgs {
     int nparts, C;
     float* rshift; float* rinvz;       // final (may be null when only the local pair is wanted)
     float* pair_out;           // [2][C] local (max, Z) for the cross-GPU exchange, or null
-    const float* fgate; float* rscale; // rscale = rinvz * f_c (or = rinvz)
+    const float* fgate; float* rscale; // forward log2-domain lse: (max + ln Z - ln f_c) * log2(e)
 };
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -1039,7 +1038,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
         const float iz = 1.f / z;
         a.rshift[c] = mx;
         a.rinvz[c] = iz;
-        a.rscale[c] = a.fgate ? iz * a.fgate[c] : iz;
+        a.rscale[c] = (mx + tg_log(z) - (a.fgate ? tg_log(a.fgate[c]) : 0.f)) * TG_LOG2E;   // log2-domain lse for the forward
     }
 }
 
