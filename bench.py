@@ -83,11 +83,19 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("TG_BENCH_BACKEND", "nccl")       # "gloo": plumbing smoke test of the N > 1 path on a 1-GPU box
+    if world > 1 and backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev}); RCCL cannot share a device between ranks")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from tangram_amd.engine import HipMapperEngine
     from tangram_amd.sharded import ShardedMapperEngine, shard_bounds
