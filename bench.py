@@ -42,6 +42,16 @@ def kernel_model(name, C, K, V):
     return None, None
 
 
+def pmc_traffic(kernel, precision):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE), or None."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return tab[precision][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(C, K, V, seed=0):
     """The reference's CPU path (PyTorch port in oracle/torch_port.py, same op sequence) on a bounded sample."""
     from oracle.torch_port import TorchPortMapper
@@ -71,6 +81,7 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--shape", default=None, help="override C,K,V (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short runs of the other GEMM precisions")
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile edge (128 or 256); 0 = automatic")
     args = ap.parse_args()
@@ -120,7 +131,6 @@ def main():
         del M0
         run = lambda n: sh.run(n, lr)
         core = sh.eng
-    del w
     torch.cuda.empty_cache()
 
     def fence():
@@ -150,6 +160,28 @@ def main():
     torch.cuda.synchronize(device)
     main_loss = float(hist[0, 1].item())
 
+    # the other GEMM precisions on the same inputs (reported beside the headline, never as `value`)
+    alt = {}
+    if world == 1 and not args.no_alt:
+        del eng, core
+        torch.cuda.empty_cache()
+        for prec in [p for p in ("bf16x3", "bf16", "fp32") if p != args.precision]:
+            M0 = init_logits(C, V, device, seed=42)
+            e2 = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=prec, lambdas=lam)
+            del M0
+            n2 = max(4, args.steps // 4)
+            e2.step(2, lr)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            e2.step(n2, lr)
+            torch.cuda.synchronize(device)
+            dt = (time.perf_counter() - t1) / n2
+            alt[prec] = {"value": 1.0 / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt, "steps": n2, "dtype": DTYPE_NAME[prec]}
+            e2.close()
+            del e2
+            torch.cuda.empty_cache()
+    del w
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         its = args.steps / elapsed
@@ -167,11 +199,11 @@ def main():
             t_m = dom["alg_GFLOP"] * 1e9 / MFMA_PEAK[args.precision]
             if t_h >= t_m:
                 roof = {"kernel": dom["name"], "bound": "hbm", "achieved": dom["alg_GB"] / t / 1e3, "peak": HBM_PEAK / 1e12,
-                        "unit": "TB/s", "frac": (dom["alg_GB"] * 1e9 / t) / HBM_PEAK, "traffic": None}
+                        "unit": "TB/s", "frac": (dom["alg_GB"] * 1e9 / t) / HBM_PEAK, "traffic": pmc_traffic(dom["name"], args.precision)}
             else:
                 roof = {"kernel": dom["name"], "bound": "mfma", "achieved": dom["alg_GFLOP"] / t / 1e3,
                         "peak": MFMA_PEAK[args.precision] / 1e12, "unit": "TFLOP/s",
-                        "frac": (dom["alg_GFLOP"] * 1e9 / t) / MFMA_PEAK[args.precision], "traffic": None}
+                        "frac": (dom["alg_GFLOP"] * 1e9 / t) / MFMA_PEAK[args.precision], "traffic": pmc_traffic(dom["name"], args.precision)}
         bytes_alg = 24.0 * C * V + 8.0 * (C * K + V * K)          # SURVEY 8(d), whole iteration, all GPUs
         flops_alg = 4.0 * C * V * K
         out = {
@@ -189,6 +221,7 @@ def main():
                                    "hbm_frac": bytes_alg * its / HBM_PEAK / world,
                                    "mfma_frac": flops_alg * its / MFMA_PEAK[args.precision] / world},
             "kernels": kern,
+            "alt_precisions": alt,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -69,6 +69,8 @@ typedef struct tg_config {
     float lambda_ct_islands;                            /* cell-type islands (:40, :242-248); needs N, N^T, ct_encode   */
     int32_t n_cell_types;                               /* T: columns of ct_encode */
     int32_t nnz_w, nnz_n;                               /* non-zeros of the two spot graphs */
+    float lambda_getis_ord, lambda_moran, lambda_geary; /* spatial autocorrelation terms (:35-37, :159-187, :251-263); need Ws, Ws^T */
+    int32_t nnz_s;                                      /* non-zeros of spatial_weights */
     float beta1, beta2, eps;                            /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 (:373) */
 } tg_config;
 
@@ -95,13 +97,17 @@ typedef struct tg_inputs {
     const int32_t* wt_indptr; const int32_t* wt_indices; const float* wt_data;
     const int32_t* n_indptr;  const int32_t* n_indices;  const float* n_data;
     const int32_t* nt_indptr; const int32_t* nt_indices; const float* nt_data;
+    /* Ws = spatial_weights (:139-141) and its transpose, for the Getis-Ord / Moran / Geary terms */
+    const int32_t* s_indptr;  const int32_t* s_indices;  const float* s_data;
+    const int32_t* st_indptr; const int32_t* st_indices; const float* st_data;
 } tg_inputs;
 
 typedef struct tg_mapper tg_mapper;
 
 /* indices into a history row (floats); unused terms are NaN like the reference's filtered terms (:301) */
 enum { TG_H_TOTAL = 0, TG_H_MAIN = 1, TG_H_VG = 2, TG_H_KL = 3, TG_H_ENTROPY = 4, TG_H_L1 = 5, TG_H_L2 = 6,
-       TG_H_NB = 7, TG_H_CT = 8, TG_H_COUNT = 9, TG_H_FREG = 10, TG_H_NTERMS = 16 };
+       TG_H_NB = 7, TG_H_CT = 8, TG_H_COUNT = 9, TG_H_FREG = 10, TG_H_GETIS = 11, TG_H_MORAN = 12, TG_H_GEARY = 13,
+       TG_H_NTERMS = 16 };
 
 /* exchange buffers of the spot-sharded multi-GPU path (device pointers inside `workspace`) */
 enum { TG_X_GENESTAT = 0,   /* [2][Kp]  per-gene (dot, |Ghat|^2) partial sums   -> all-reduce(sum) */

@@ -35,6 +35,8 @@ CASES = {
     "cells_ragged": (131, 37, 53, 5, 40, "cells", dict(lambda_g1=1, lambda_d=1, lambda_g2=1)),
     "cells_spatial": (200, 40, 100, 6, 40, "spatial",
                       dict(lambda_g1=1, lambda_d=1, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17)),
+    "cells_autocorr": (80, 20, 36, 10, 30, "autocorr",
+                       dict(lambda_g1=1, lambda_d=1, lambda_getis_ord=0.6, lambda_moran=0.4, lambda_geary=0.3)),
     "cells_val": (100, 24, 40, 9, 20, "cells", dict(lambda_g1=1, lambda_d=1, lambda_g2=0.5, val_each=2)),
     "constrained": (150, 40, 60, 7, 50, "constrained",
                     dict(lambda_d=1, lambda_g1=1, lambda_g2=1, lambda_count=1, lambda_f_reg=1, target_count=40)),
@@ -69,6 +71,9 @@ def build_inputs(name):
         args["voxel_weights"] = grid_graph(V, standardized=True, self_inclusion=True)
         args["neighborhood_filter"] = grid_graph(V, standardized=False, self_inclusion=False)
         args["ct_encode"] = data["ct_encode"]
+    if mode == "autocorr":
+        # one matrix serves all three indicators in the reference (mapping_optimizer.py:139-141); row-standardised, no self loops
+        args["spatial_weights"] = grid_graph(V, standardized=True, self_inclusion=False)
     args.update(kw)
     return args, epochs, mode
 

@@ -116,6 +116,7 @@ class OracleMapper:
                  lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0,
                  lambda_neighborhood_g1=0.0, voxel_weights=None,
                  lambda_ct_islands=0.0, neighborhood_filter=None, ct_encode=None,
+                 lambda_getis_ord=0.0, lambda_moran=0.0, lambda_geary=0.0, spatial_weights=None,
                  M0=None, random_state=None, dtype=np.float64):
         self.dt = np.dtype(dtype)
         f = self.dt.type
@@ -139,6 +140,74 @@ class OracleMapper:
         self.t = 0
         if self.W is not None:
             self.WG = self.W @ self.G          # constant (mapping_optimizer.py:236 recomputes it)
+        # spatial autocorrelation terms (mapping_optimizer.py:159-187, :251-263)
+        self.lgo, self.lmo, self.lge = f(lambda_getis_ord), f(lambda_moran), f(lambda_geary)
+        self.Ws = None if spatial_weights is None else np.asarray(spatial_weights, dtype=np.float32).astype(self.dt)
+        if self.lgo > 0 or self.lmo > 0 or self.lge > 0:
+            self.ref_getis, self.ref_moran, self.ref_geary = self._indicators(self.G)     # :144
+
+    def _indicators(self, X):
+        """_spatial_local_indicators (mapping_optimizer.py:159-187) on a V x K matrix."""
+        V = X.shape[0]
+        Ws = self.Ws
+        getis = moran = geary = None
+        if self.lgo > 0:
+            getis = (Ws @ X) / X.sum(axis=0)                                   # :171
+        if self.lmo > 0:
+            z = X - X.mean(axis=0)
+            moran = (V * z * (Ws @ z)) / (z * z).sum(axis=0)                    # :175-176
+        if self.lge > 0:
+            m2 = ((X - X.mean(axis=0)) ** 2).sum(axis=0) / (V - 1)              # :181
+            r, c = Ws.sum(axis=1), Ws.sum(axis=0)
+            A = (c[:, None] * X * X).sum(axis=0) + (r[:, None] * X * X).sum(axis=0) - 2 * (X * (Ws @ X)).sum(axis=0)
+            geary = A / (2 * m2)                                                # :182-185 (sum_ij w_ij (x_j - x_i)^2)
+        return getis, moran, geary
+
+    def _autocorr_terms(self, Ghat):
+        """values and d(-lambda * term)/dGhat of the Getis-Ord / Moran / Geary terms (:251-263, total :266-270)."""
+        V = Ghat.shape[0]
+        Ws = self.Ws
+        dG = np.zeros_like(Ghat)
+        vals = {}
+        if self.lgo > 0:
+            s = Ghat.sum(axis=0)
+            Y = Ws @ Ghat
+            pred = Y / s
+            val, g, _ = cos_mean_and_grad(pred, self.ref_getis, 0)             # cos is symmetric in its arguments
+            vals["getis"] = val
+            dY = g / s
+            ds = -(g * Y).sum(axis=0) / (s * s)
+            dG += -self.lgo * (Ws.T @ dY + ds[None, :])
+        if self.lmo > 0:
+            mu = Ghat.mean(axis=0)
+            z = Ghat - mu
+            u = Ws @ z
+            q = (z * z).sum(axis=0)
+            I = V * z * u / q
+            val, g, _ = cos_mean_and_grad(I, self.ref_moran, 0)
+            vals["moran"] = val
+            dq = -(g * V * z * u).sum(axis=0) / (q * q)
+            dz = V * g * u / q + Ws.T @ (V * g * z / q) + 2 * z * dq[None, :]
+            dG += -self.lmo * (dz - dz.mean(axis=0))
+        if self.lge > 0:
+            mu = Ghat.mean(axis=0)
+            xc = Ghat - mu
+            m2 = (xc * xc).sum(axis=0) / (V - 1)
+            r, c = Ws.sum(axis=1), Ws.sum(axis=0)
+            Y, Z = Ws @ Ghat, Ws.T @ Ghat
+            A = ((c + r)[:, None] * Ghat * Ghat).sum(axis=0) - 2 * (Ghat * Y).sum(axis=0)
+            p = A / (2 * m2)
+            ref = self.ref_geary
+            npn = max(np.sqrt((p * p).sum()), EPS_COS)
+            nrn = max(np.sqrt((ref * ref).sum()), EPS_COS)
+            cosv = (p * ref).sum() / (npn * nrn)
+            vals["geary"] = cosv
+            gp = ref / (npn * nrn) - cosv * p / (npn * npn)                     # d cos / d p_k
+            dA = 2 * ((c + r)[:, None] * Ghat - Z - Y)
+            dm2 = 2 * xc / (V - 1)
+            dp = dA / (2 * m2) - (A / (2 * m2 * m2)) * dm2
+            dG += -self.lge * gp[None, :] * dp
+        return vals, dG
 
     # -- forward + analytic backward -----------------------------------------------------------
     def loss_and_grad(self):
@@ -205,6 +274,14 @@ class OracleMapper:
             dct = mask - self.N.T @ mask
             dP += self.lct * (self.E @ dct.T)
             terms["ct_island"] = isl
+
+        if self.lgo > 0 or self.lmo > 0 or self.lge > 0:       # :251-263; total -= each term (:270)
+            vals, dGa = self._autocorr_terms(Ghat)
+            dGhat = dGhat + dGa
+            for nm, lamv in (("getis", self.lgo), ("moran", self.lmo), ("geary", self.lge)):
+                if nm in vals:
+                    total = total - lamv * vals[nm]
+                    terms[nm + "_sim"] = vals[nm]
 
         dP += S @ dGhat.T                                      # second GEMM (autograd of :202)
         r = (P * dP).sum(axis=1, keepdims=True)

@@ -11,7 +11,7 @@ grep -oE "^\s*(Name|name)\s*:\s*\S+" $O/counters_list.txt | awk '{print $NF}' | 
 i=0
 while read -r GROUP; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d $O/g$i -o p -- python $R/bench.py --steps 3 --warmup 1 --precision $P --no-cpu-baseline > $O/g$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d $O/g$i -o p -- python $R/bench.py --steps 3 --warmup 1 --precision $P --no-cpu-baseline --no-alt > $O/g$i.log 2>&1
   echo "group $i [$GROUP] rc=$?"
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES

@@ -13,17 +13,17 @@ if [ -z "$2" ]; then
   tail -15 $O/pytest_gpu.log
 fi
 for P in bf16x3 bf16 fp32; do
-  echo "== bench $P"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
+  echo "== bench $P"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
 done
 if [ -f $R/build/libtangram_hip_alt.so ]; then
 for P in bf16x3 bf16; do
-  echo "== bench $P ALT lib"; TANGRAM_AMD_LIB=$R/build/libtangram_hip_alt.so timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline > $O/bench_${P}_alt.json 2> $O/bench_${P}_alt.err; echo "rc=$?"
+  echo "== bench $P ALT lib"; TANGRAM_AMD_LIB=$R/build/libtangram_hip_alt.so timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/bench_${P}_alt.json 2> $O/bench_${P}_alt.err; echo "rc=$?"
 done
 fi
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp
 for P in bf16x3 bf16; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$P -o r -- python $R/bench.py --steps 10 --warmup 2 --precision $P --no-cpu-baseline > $O/rocprof_$P.log 2>&1; echo "rocprof $P rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$P -o r -- python $R/bench.py --steps 10 --warmup 2 --precision $P --no-cpu-baseline --no-alt > $O/rocprof_$P.log 2>&1; echo "rocprof $P rc=$?"
 done
 cd $R
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -size +1M -delete

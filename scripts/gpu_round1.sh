@@ -10,12 +10,12 @@ echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest gpu"; timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
 tail -25 $O/pytest_gpu.log
 echo "== bench bf16x3"; timeout 900 python bench.py --steps 30 --warmup 5 > $O/bench_bf16x3.json 2> $O/bench_bf16x3.err; echo "rc=$?"; tail -c 1500 $O/bench_bf16x3.json
-echo "== bench bf16"; timeout 600 python bench.py --steps 30 --warmup 5 --precision bf16 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err; echo "rc=$?"
-echo "== bench fp32"; timeout 600 python bench.py --steps 10 --warmup 2 --precision fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "rc=$?"
+echo "== bench bf16"; timeout 600 python bench.py --steps 30 --warmup 5 --precision bf16 --no-cpu-baseline --no-alt > $O/bench_bf16.json 2> $O/bench_bf16.err; echo "rc=$?"
+echo "== bench fp32"; timeout 600 python bench.py --steps 10 --warmup 2 --precision fp32 --no-cpu-baseline --no-alt > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "rc=$?"
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bf16x3 -o r1 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/rocprof_bf16x3.log 2>&1; echo "rocprof rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o r1 -- python $R/bench.py --steps 10 --warmup 2 --precision bf16 --no-cpu-baseline > $O/rocprof_bf16.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bf16x3 -o r1 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-alt > $O/rocprof_bf16x3.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o r1 -- python $R/bench.py --steps 10 --warmup 2 --precision bf16 --no-cpu-baseline --no-alt > $O/rocprof_bf16.log 2>&1; echo "rocprof rc=$?"
 cd $R
 # keep only the small summaries
 find $O -name "*.csv" -size +2M -delete

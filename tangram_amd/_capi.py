@@ -17,7 +17,7 @@ TG_ABI_VERSION = 1
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 H_NTERMS = 16
-H_TOTAL, H_MAIN, H_VG, H_KL, H_ENTROPY, H_L1, H_L2, H_NB, H_CT, H_COUNT, H_FREG = range(11)
+H_TOTAL, H_MAIN, H_VG, H_KL, H_ENTROPY, H_L1, H_L2, H_NB, H_CT, H_COUNT, H_FREG, H_GETIS, H_MORAN, H_GEARY = range(14)
 X_GENESTAT, X_GNORM2, X_ROWQ, X_ROWPAIR = range(4)
 
 
@@ -29,6 +29,7 @@ class TgConfig(ct.Structure):
                 ("lambda_g1", "lambda_d", "lambda_g2", "lambda_r", "lambda_l1", "lambda_l2",
                  "lambda_count", "lambda_f_reg", "target_count", "lambda_neighborhood_g1", "lambda_ct_islands")] + \
                [(n, ct.c_int32) for n in ("n_cell_types", "nnz_w", "nnz_n")] + \
+               [(n, ct.c_float) for n in ("lambda_getis_ord", "lambda_moran", "lambda_geary")] + [("nnz_s", ct.c_int32)] + \
                [(n, ct.c_float) for n in ("beta1", "beta2", "eps")]
 
 
@@ -40,7 +41,8 @@ class TgSizes(ct.Structure):
 class TgInputs(ct.Structure):
     _fields_ = [(n, ct.c_void_p) for n in ("S_dev", "G_dev", "d_dev", "d_source_dev", "M0_dev", "F0_dev", "ct_encode_dev",
                                            "w_indptr", "w_indices", "w_data", "wt_indptr", "wt_indices", "wt_data",
-                                           "n_indptr", "n_indices", "n_data", "nt_indptr", "nt_indices", "nt_data")]
+                                           "n_indptr", "n_indices", "n_data", "nt_indptr", "nt_indices", "nt_data",
+                                           "s_indptr", "s_indices", "s_data", "st_indptr", "st_indices", "st_data")]
 
 
 _lib = None

@@ -57,15 +57,17 @@ struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
     size_t o_Sk, o_St, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
         o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X,
-        o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[4][3], total;
-    int T_ct, Tp, has_nb, has_ct;
+        o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[6][3],
+        o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
+        o_accmpart, o_accm, o_actnorm, total;
+    int T_ct, Tp, has_nb, has_ct, has_ac;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
 static int tg_choose_splits(int tiles, int nsteps, int slots) {
     int best = 1;
     double best_eff = 0.0;
-    for (int s = 1; s <= 8 && s <= nsteps; ++s) {
+    for (int s = 1; s <= 32 && s <= nsteps / 8; ++s) {          // keep >= 8 contraction steps per workgroup
         const long w = (long)tiles * s;
         const long waves = (w + slots - 1) / slots;
         const double eff = (double)w / (double)(waves * slots);
@@ -93,8 +95,10 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 1024) ? 256 : 128);
     L->has_nb = cfg->lambda_neighborhood_g1 > 0.f;
     L->has_ct = cfg->lambda_ct_islands > 0.f;
-    if ((L->has_nb || L->has_ct) && cfg->mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_INVALID, "spatial terms exist only in Mapper (mapping_utils.py:366-375 ignores them in constrained mode)");
-    if ((L->has_nb || L->has_ct) && cfg->n_spots_total > 0 && cfg->n_spots_total != cfg->n_spots)
+    L->has_ac = cfg->lambda_getis_ord > 0.f || cfg->lambda_moran > 0.f || cfg->lambda_geary > 0.f;
+    if (L->has_ac && cfg->nnz_s < 1) return tg_fail(TG_ERR_INVALID, "the spatial autocorrelation terms need the spatial_weights graph");
+    if ((L->has_nb || L->has_ct || L->has_ac) && cfg->mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_INVALID, "spatial terms exist only in Mapper (mapping_utils.py:366-375 ignores them in constrained mode)");
+    if ((L->has_nb || L->has_ct || L->has_ac) && cfg->n_spots_total > 0 && cfg->n_spots_total != cfg->n_spots)
         return tg_fail(TG_ERR_UNSUPPORTED, "spatial terms need the whole spot graph on one GPU (no halo exchange yet)");
     if (L->has_ct && cfg->n_cell_types < 1) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs n_cell_types >= 1");
     if (L->has_nb && cfg->nnz_w < 1) return tg_fail(TG_ERR_INVALID, "lambda_neighborhood_g1 > 0 needs the voxel_weights graph");
@@ -143,7 +147,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_X = take((size_t)L->C * L->Vp * 4);
     L->o_gfrac = take((size_t)L->Kp * 4);
     L->o_rowent = take((size_t)L->Cp * 4);
-    if (L->has_nb || L->has_ct) L->o_extra = take((size_t)L->Vr * L->Kp * 4);
+    if (L->has_nb || L->has_ct || L->has_ac) L->o_extra = take((size_t)L->Vr * L->Kp * 4);
     if (L->has_nb) {
         L->o_WG = take((size_t)L->Vr * L->Kp * 4);
         L->o_Y = take((size_t)L->Vr * L->Kp * 4);
@@ -156,9 +160,16 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
         L->o_ctmask = take((size_t)L->Vr * L->Tp * 4);
         L->o_ctpart = take((size_t)L->Vr * 4);
     }
-    for (int gph = 0; gph < 4; ++gph) {           // 0: W, 1: W^T, 2: N, 3: N^T
-        const bool on = gph < 2 ? L->has_nb : L->has_ct;
-        const size_t nnz = gph < 2 ? (size_t)cfg->nnz_w : (size_t)cfg->nnz_n;
+    if (L->has_ac) {
+        const size_t vk = (size_t)L->Vr * L->Kp * 4, kp = (size_t)L->Kp * 4;
+        L->o_acY = take(vk); L->o_acZ = take(vk); L->o_acTg = take(vk); L->o_acTm = take(vk); L->o_acB1 = take(vk); L->o_acD = take(vk);
+        L->o_acrefp = take(kp); L->o_acr = take((size_t)L->Vr * 4); L->o_acrc = take((size_t)L->Vr * 4);
+        L->o_acpart = take((size_t)L->nrb * TGAC_NSTAT * kp); L->o_acstat = take(TGAC_NSTAT * kp); L->o_acstat2 = take(3 * kp);
+        L->o_accoef = take(TGAC_NCOEF * kp); L->o_accmpart = take((size_t)L->nrb * kp); L->o_accm = take(kp); L->o_actnorm = take(4 * kp);
+    }
+    for (int gph = 0; gph < 6; ++gph) {           // 0: W, 1: W^T, 2: N, 3: N^T, 4: Ws, 5: Ws^T
+        const bool on = gph < 2 ? L->has_nb : (gph < 4 ? L->has_ct : L->has_ac);
+        const size_t nnz = gph < 2 ? (size_t)cfg->nnz_w : (gph < 4 ? (size_t)cfg->nnz_n : (size_t)cfg->nnz_s);
         if (!on) continue;
         L->o_csr[gph][0] = take((size_t)(L->V + 1) * 4);
         L->o_csr[gph][1] = take(nnz * 4);
@@ -284,12 +295,13 @@ static TgCsr tg_csr(const tg_mapper* m, int gph) {
 // spatial terms, set-up: library-owned copies of the CSR graphs, W G and |W G_k|^2 (constant: :236 recomputes it every iteration)
 static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
     const TgLayout& L = m->L;
-    const void* src[4][3] = {{in->w_indptr, in->w_indices, in->w_data}, {in->wt_indptr, in->wt_indices, in->wt_data},
-                             {in->n_indptr, in->n_indices, in->n_data}, {in->nt_indptr, in->nt_indices, in->nt_data}};
-    for (int gph = 0; gph < 4; ++gph) {
-        const bool on = gph < 2 ? L.has_nb : L.has_ct;
+    const void* src[6][3] = {{in->w_indptr, in->w_indices, in->w_data}, {in->wt_indptr, in->wt_indices, in->wt_data},
+                             {in->n_indptr, in->n_indices, in->n_data}, {in->nt_indptr, in->nt_indices, in->nt_data},
+                             {in->s_indptr, in->s_indices, in->s_data}, {in->st_indptr, in->st_indices, in->st_data}};
+    for (int gph = 0; gph < 6; ++gph) {
+        const bool on = gph < 2 ? L.has_nb : (gph < 4 ? L.has_ct : L.has_ac);
         if (!on) continue;
-        const size_t nnz = gph < 2 ? (size_t)m->cfg.nnz_w : (size_t)m->cfg.nnz_n;
+        const size_t nnz = gph < 2 ? (size_t)m->cfg.nnz_w : (gph < 4 ? (size_t)m->cfg.nnz_n : (size_t)m->cfg.nnz_s);
         for (int j = 0; j < 3; ++j)
             if (!src[gph][j]) return tg_fail(TG_ERR_INVALID, "a spatial term is enabled but its CSR graph (or the transpose) is NULL");
         TG_CK(tg_memcpy(m->ws + L.o_csr[gph][0], src[gph][0], (size_t)(L.V + 1) * 4, m->stream));
@@ -298,7 +310,7 @@ static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
     }
     if (L.has_ct && !in->ct_encode_dev) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs ct_encode");
     if (L.has_nb) {
-        TgSpmmArgs a;
+        TgSpmmArgs a = {};
         a.W = tg_csr(m, 0); a.A = m->fp(L.o_Gp); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
         a.Y = m->fp(L.o_WG); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
         TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
@@ -314,7 +326,7 @@ static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
 static int tg_launch_spatial_stats(tg_mapper* m) {
     const TgLayout& L = m->L;
     if (L.has_nb) {
-        TgSpmmArgs a;
+        TgSpmmArgs a = {};
         a.W = tg_csr(m, 0); a.A = m->fp(L.o_Ghat); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
         a.Y = m->fp(L.o_Y); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
         TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
@@ -335,11 +347,79 @@ static int tg_launch_spatial_stats(tg_mapper* m) {
     return TG_OK;
 }
 
+// ---- spatial autocorrelation terms (Getis-Ord / Moran / Geary) --------------------------------------------------
+static TgAcArgs tg_ac_args(tg_mapper* m, const float* X, bool setup, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgAcArgs a = {};
+    a.X = X; a.Y = m->fp(L.o_acY); a.Z = m->fp(L.o_acZ); a.r = m->fp(L.o_acr); a.rc = m->fp(L.o_acrc);
+    a.Tg = m->fp(L.o_acTg); a.Tm = m->fp(L.o_acTm); a.refp = m->fp(L.o_acrefp);
+    a.part = m->fp(L.o_acpart); a.stat = m->fp(L.o_acstat); a.stat2 = m->fp(L.o_acstat2); a.coef = m->fp(L.o_accoef);
+    a.B1 = m->fp(L.o_acB1); a.D = m->fp(L.o_acD); a.cmpart = m->fp(L.o_accmpart); a.cm = m->fp(L.o_accm);
+    a.hist = hist_row ? hist_row : m->fp(L.o_scal);
+    a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.setup = setup ? 1 : 0;
+    a.lam_getis = m->cfg.lambda_getis_ord; a.lam_moran = m->cfg.lambda_moran; a.lam_geary = m->cfg.lambda_geary;
+    return a;
+}
+
+// Y = Ws X (+ local Geary sums into D), first and second stage statistics
+static void tg_ac_indicators(tg_mapper* m, TgAcArgs& a) {
+    const TgLayout& L = m->L;
+    const int nrb = (L.V + TG_RB - 1) / TG_RB, kb = (L.Kp + 255) / 256;
+    TgSpmmArgs sp = {};
+    sp.W = tg_csr(m, 4); sp.A = a.X; sp.Y = m->fp(L.o_acY); sp.E = m->fp(L.o_acD); sp.V = L.V; sp.Kp = L.Kp; sp.k_begin = 0; sp.k_end = L.K;
+    TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, sp);
+    TG_LAUNCH(tg_ac_stats1, nrb, 1, 256, 0, m->stream, a);
+    TG_LAUNCH(tg_stat_reduce, kb, 1, 256, 0, m->stream, (const float*)a.part, nrb, (int)TGAC_NSTAT, L.Kp, a.stat);
+    TG_LAUNCH(tg_ac_stats2, nrb, 1, 256, 0, m->stream, a);
+    TG_LAUNCH(tg_stat_reduce, kb, 1, 256, 0, m->stream, (const float*)a.part, nrb, 3, L.Kp, a.stat2);
+}
+
+static int tg_setup_autocorr(tg_mapper* m) {
+    const TgLayout& L = m->L;
+    const int nrb = (L.V + TG_RB - 1) / TG_RB;
+    TG_LAUNCH(tg_csr_rowsum, (L.V + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 4), L.V, m->fp(L.o_acr), 0);
+    TG_LAUNCH(tg_csr_rowsum, (L.V + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 4), L.V, m->fp(L.o_acrc), 0);
+    TG_LAUNCH(tg_csr_rowsum, (L.V + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 5), L.V, m->fp(L.o_acrc), 1);
+    TgAcArgs a = tg_ac_args(m, m->fp(L.o_Gp), true, nullptr);       // indicators of G: the references (:144)
+    tg_ac_indicators(m, a);
+    TG_LAUNCH(tg_ac_refs, nrb, 1, 256, 0, m->stream, a);
+    // |Tg_k|^2 and |Tm_k|^2 (rows 0 and 2 of tnorm)
+    TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tg, (const float*)a.Tg, L.V, L.Kp, a.part);
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm));
+    TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tm, (const float*)a.Tm, L.V, L.Kp, a.part);
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm) + 2 * (size_t)L.Kp);
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+// per iteration, after tg_loss_finalize (which starts the history row)
+static int tg_launch_autocorr(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    const int nrb = (L.V + TG_RB - 1) / TG_RB, kb = (L.Kp + 255) / 256;
+    TgAcArgs a = tg_ac_args(m, m->fp(L.o_Ghat), false, hist_row);
+    tg_ac_indicators(m, a);
+    if (a.lam_geary > 0.f) {
+        TgSpmmArgs sz = {};
+        sz.W = tg_csr(m, 5); sz.A = a.X; sz.Y = m->fp(L.o_acZ); sz.V = L.V; sz.Kp = L.Kp; sz.k_begin = 0; sz.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, sz);
+    }
+    TgAcFinArgs f; f.a = a; f.tnorm = m->fp(L.o_actnorm);
+    TG_LAUNCH(tg_ac_finalize, 1, 1, 1024, 64, m->stream, f);
+    TG_LAUNCH(tg_ac_grad, nrb, 1, 256, 0, m->stream, a);
+    TG_LAUNCH(tg_stat_reduce, kb, 1, 256, 0, m->stream, (const float*)a.cmpart, nrb, 1, L.Kp, a.cm);
+    TgSpmmArgs sg = {};       // extra[:, :K] (+)= Ws^T B1 + D - cm
+    sg.W = tg_csr(m, 5); sg.A = a.B1; sg.Y = m->fp(L.o_extra); sg.V = L.V; sg.Kp = L.Kp; sg.k_begin = 0; sg.k_end = L.K;
+    sg.accumulate = L.has_nb ? 1 : 0; sg.addD = a.D; sg.addc = a.cm;
+    TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, sg);
+    tg_prof_mark(m, "tg_spatial_autocorr");
+    return TG_OK;
+}
+
 // part 2 (after tg_loss_finalize): extra[:, :K] = W^T (nbcoef0 * WG + nbcoef1 * W Ghat)
 static int tg_launch_spatial_grad(tg_mapper* m) {
     const TgLayout& L = m->L;
     if (L.has_nb) {
-        TgSpmmArgs a;
+        TgSpmmArgs a = {};
         a.W = tg_csr(m, 1); a.A = m->fp(L.o_WG); a.B = m->fp(L.o_Y); a.ca = m->fp(L.o_nbcoef); a.cb = m->fp(L.o_nbcoef) + L.Kp;
         a.Y = m->fp(L.o_extra); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
         TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
@@ -409,7 +489,8 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
               m->fp(L.o_gnorm2), 1.f);
     TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream,
               (const float*)(m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp), L.nrb, L.Kp, m->fp(L.o_gfrac), 1.f / (float)L.V);
-    if ((L.has_nb || L.has_ct) && (rc = tg_setup_spatial(m, in))) return bail(rc);
+    if ((L.has_nb || L.has_ct || L.has_ac) && (rc = tg_setup_spatial(m, in))) return bail(rc);
+    if (L.has_ac && (rc = tg_setup_autocorr(m))) return bail(rc);
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rscale), (size_t)L.Cp, 3.0e38f);
@@ -482,10 +563,11 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 64, m->stream, f);
     tg_prof_mark(m, "tg_loss_finalize");
     if ((rcs = tg_launch_spatial_grad(m))) return rcs;
+    if (L.has_ac && (rcs = tg_launch_autocorr(m, hist_row))) return rcs;
     TgEmitArgs e;
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
-    e.extra = (L.has_nb || L.has_ct) ? m->fp(L.o_extra) : nullptr;
+    e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) : nullptr;
     e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
     TG_LAUNCH((tg_dghat_emit<PR>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
     tg_prof_mark(m, "tg_dghat_emit");

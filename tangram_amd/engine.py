@@ -40,7 +40,7 @@ class HipMapperEngine:
     def __init__(self, S, G, M0, d=None, d_source=None, F0=None, *, mode="mapper", device="cuda:0",
                  precision="bf16x3", lambdas=None, n_spots_total=None, fwd_splits=0, tile_size=0,
                  target_count=0.0, betas=(0.9, 0.999), eps=1e-8,
-                 voxel_weights=None, neighborhood_filter=None, ct_encode=None):
+                 voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
         self.device = torch.device(device)
         if self.device.type != "cuda" and not _capi.is_emulated():
             raise RuntimeError(f"tangram_amd runs on a HIP device only (got device={device!r}); there is no CPU path")
@@ -48,7 +48,8 @@ class HipMapperEngine:
             raise ValueError(f"gemm precision must be one of {sorted(_capi.PRECISIONS)}")
         self._lib = _capi.lib()
         lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0,
-                   lambda_count=1.0, lambda_f_reg=1.0, lambda_neighborhood_g1=0.0, lambda_ct_islands=0.0)
+                   lambda_count=1.0, lambda_f_reg=1.0, lambda_neighborhood_g1=0.0, lambda_ct_islands=0.0,
+                   lambda_getis_ord=0.0, lambda_moran=0.0, lambda_geary=0.0)
         lam.update(lambdas or {})
         S = _as_dev_f32(S, self.device)
         G = _as_dev_f32(G, self.device)
@@ -91,6 +92,13 @@ class HipMapperEngine:
             keep += [w, wt]
             inp.w_indptr, inp.w_indices, inp.w_data = (x.data_ptr() for x in w)
             inp.wt_indptr, inp.wt_indices, inp.wt_data = (x.data_ptr() for x in wt)
+        if lam["lambda_getis_ord"] > 0 or lam["lambda_moran"] > 0 or lam["lambda_geary"] > 0:
+            if spatial_weights is None:
+                raise ValueError("lambda_getis_ord / lambda_moran / lambda_geary > 0 need spatial_weights")
+            ws, wst, cfg.nnz_s = _csr_pair(spatial_weights, self.V, self.device)
+            keep += [ws, wst]
+            inp.s_indptr, inp.s_indices, inp.s_data = (x.data_ptr() for x in ws)
+            inp.st_indptr, inp.st_indices, inp.st_data = (x.data_ptr() for x in wst)
         if lam["lambda_ct_islands"] > 0:
             if neighborhood_filter is None or ct_encode is None:
                 raise ValueError("lambda_ct_islands > 0 needs neighborhood_filter and ct_encode")

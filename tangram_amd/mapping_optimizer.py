@@ -30,6 +30,7 @@ _PRINT_NAMES = [  # reference :286-298, with the history column each comes from
     ("Gene-voxel score", _capi.H_MAIN), ("Voxel-gene score", _capi.H_VG), ("Cell densities reg", _capi.H_KL),
     ("Entropy reg", _capi.H_ENTROPY), ("L1 reg", _capi.H_L1), ("L2 reg", _capi.H_L2),
     ("Spatial weighted score", _capi.H_NB), ("Cell type islands penalty", _capi.H_CT),
+    ("Getis-Ord score", _capi.H_GETIS), ("Moran score", _capi.H_MORAN), ("Geary score", _capi.H_GEARY),
 ]
 
 
@@ -83,9 +84,11 @@ class Mapper:
     ):
         if adata_map is not None:
             raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :151-153)")
-        for name, lam in (("lambda_getis_ord", lambda_getis_ord), ("lambda_geary", lambda_geary), ("lambda_moran", lambda_moran)):
-            if lam and lam > 0:
-                raise NotImplementedError(f"{name} > 0: the spatial autocorrelation terms are not built yet in tangram_amd")
+        lambda_getis_ord = lambda_getis_ord if (lambda_getis_ord and lambda_getis_ord > 0) else 0.0     # reference :170,:174,:179
+        lambda_moran = lambda_moran if (lambda_moran and lambda_moran > 0) else 0.0
+        lambda_geary = lambda_geary if (lambda_geary and lambda_geary > 0) else 0.0
+        if not (lambda_getis_ord or lambda_moran or lambda_geary):
+            spatial_weights = None
         if not (lambda_neighborhood_g1 and lambda_neighborhood_g1 > 0):      # reference :234: only evaluated when > 0
             lambda_neighborhood_g1, voxel_weights = 0.0, None
         if not (lambda_ct_islands and lambda_ct_islands > 0):                # reference :242
@@ -112,11 +115,12 @@ class Mapper:
             M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)
         lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
                        lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2,
-                       lambda_neighborhood_g1=lambda_neighborhood_g1, lambda_ct_islands=lambda_ct_islands)
+                       lambda_neighborhood_g1=lambda_neighborhood_g1, lambda_ct_islands=lambda_ct_islands,
+                       lambda_getis_ord=lambda_getis_ord, lambda_moran=lambda_moran, lambda_geary=lambda_geary)
         self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
                                        mode="mapper", device=self.device, precision=gemm_precision, lambdas=lambdas,
                                        voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
-                                       ct_encode=_to_numpy_f32(ct_encode))
+                                       ct_encode=_to_numpy_f32(ct_encode), spatial_weights=spatial_weights)
 
     # ------------------------------------------------------------------------------------------------
     def _history_dict(self, hist):

@@ -10,8 +10,8 @@ Deliberate differences from the reference, all documented in DESIGN.md:
   * a dense `adata_sc.X` works (the reference calls `.toarray()` on an ndarray at :262).
   * the per-gene training scores (:402-410) are computed from the projection P^T S evaluated on the GPU instead
     of a NumPy `adata_map.X.T @ S` on the host.
-  * the neighbourhood and cell-type-island terms take the spot graph as scipy CSR (tangram_amd/spatial_weights.py)
-    instead of dense V x V matrices; Getis-Ord, Moran and Geary raise NotImplementedError.
+  * the spatial terms (neighbourhood, cell-type islands, Getis-Ord, Moran, Geary) take the spot graph as scipy CSR
+    (tangram_amd/spatial_weights.py) instead of dense V x V matrices.
 Extra keyword: `gemm_precision` (see tangram_amd.mapping_optimizer).
 """
 from __future__ import annotations
@@ -167,11 +167,7 @@ def map_cells_to_space(
     print_each = 100 if verbose else None                                     # :312-315
 
     if mode in ["cells", "clusters"]:
-        for name, lam in (("lambda_getis_ord", lambda_getis_ord), ("lambda_moran", lambda_moran),
-                          ("lambda_geary", lambda_geary)):
-            if lam and lam > 0:
-                raise NotImplementedError(f"{name} > 0 is not built yet in tangram_amd (spatial autocorrelation terms)")
-        voxel_weights, neighborhood_filter, ct_encode = None, None, None      # :318-329
+        voxel_weights, neighborhood_filter, ct_encode, spatial_weights = None, None, None, None      # :318-329
         if lambda_neighborhood_g1 > 0:
             voxel_weights = sw.spatial_weights(adata_sp, standardized=True, self_inclusion=True)
         if lambda_ct_islands > 0:
@@ -179,11 +175,17 @@ def map_cells_to_space(
                 raise ValueError("cluster_label must be specified for the cell type island extension.")
             neighborhood_filter = sw.spatial_weights(adata_sp, standardized=False, self_inclusion=False)
             ct_encode, _ = sw.one_hot_encoding(adata_sc.obs[cluster_label])
+        if lambda_moran > 0 or lambda_geary > 0:
+            spatial_weights = sw.spatial_weights(adata_sp, standardized=True, self_inclusion=False)
+        if lambda_getis_ord > 0:                                              # overrides the matrix above, like :328-329
+            spatial_weights = sw.spatial_weights(adata_sp, standardized=False, self_inclusion=True)
         hyperparameters = {                                                   # :331-348
             "lambda_d": lambda_d, "lambda_g1": lambda_g1, "lambda_g2": lambda_g2, "lambda_r": lambda_r,
             "lambda_l1": lambda_l1, "lambda_l2": lambda_l2, "d_source": d_source,
             "lambda_neighborhood_g1": lambda_neighborhood_g1, "voxel_weights": voxel_weights,
             "lambda_ct_islands": lambda_ct_islands, "neighborhood_filter": neighborhood_filter, "ct_encode": ct_encode,
+            "lambda_getis_ord": lambda_getis_ord, "lambda_moran": lambda_moran, "lambda_geary": lambda_geary,
+            "spatial_weights": spatial_weights,
         }
         logging.info("Begin training with {} genes and {} density_prior in {} mode...".format(
             len(training_genes), d_str, mode))

@@ -29,7 +29,8 @@ def sim():
     ("constrained", "fp32", 8),          # MapperConstrained: filter F, count / f_reg terms
     ("constrained_entropy", "bf16x3", 6),
     ("cells_val", "bf16x3", 7),          # val_each: validation metrics of _val_loss_fn
-    ("cells_spatial", "fp32", 6),        # neighbourhood-weighted gene term + cell-type islands on a CSR spot graph
+    ("cells_spatial", "fp32", 6),
+    ("cells_autocorr", "fp32", 6),       # Getis-Ord + Moran + Geary on a CSR spot graph        # neighbourhood-weighted gene term + cell-type islands on a CSR spot graph
 ])
 def test_emulated_kernels_match_reference(sim, name, precision, epochs):
     res = pc.run_case(name, "cpu", precision, epochs=epochs)
