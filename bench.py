@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the short runs of the other GEMM precisions")
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile edge (128 or 256); 0 = automatic")
+    ap.add_argument("--bands", type=int, default=0, help="cell bands of the 3-stream pipeline (0 = automatic, 1 = sequential schedule)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +120,7 @@ def main():
     if world == 1:
         M0 = init_logits(C, V, device, seed=42)
         eng = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=args.precision, lambdas=lam,
-                              fwd_splits=args.splits, tile_size=args.tile)
+                              fwd_splits=args.splits, tile_size=args.tile, pipeline_bands=args.bands)
         del M0
         run = lambda n: eng.step(n, lr)
         core = eng
@@ -140,11 +141,18 @@ def main():
 
     run(args.warmup)
     fence()
-    core.profile(True)                              # HIP events after every kernel of the timed steps (no sync)
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps)                                 # timed region: the product schedule (3-stream cell-band pipeline on 1 GPU)
     fence()
     elapsed = time.perf_counter() - t0
+    # per-kernel durations: HIP events after every kernel on the kernel's stream.  Event-bracketing needs the kernels on
+    # ONE stream, so this pass runs the sequential schedule (same kernels, same launches, no overlap between them).
+    nprof = max(4, min(args.steps, 20))
+    core.profile(True)
+    t1 = time.perf_counter()
+    run(nprof)
+    fence()
+    seq_elapsed = time.perf_counter() - t1
     prof = core.profile_read()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -221,6 +229,8 @@ def main():
                                    "hbm_frac": bytes_alg * its / HBM_PEAK / world,
                                    "mfma_frac": flops_alg * its / MFMA_PEAK[args.precision] / world},
             "kernels": kern,
+            "kernels_pass": {"schedule": "sequential (one stream, HIP event after every kernel)", "steps": nprof,
+                             "ms_per_step": 1e3 * seq_elapsed / nprof, "value": nprof / seq_elapsed},
             "alt_precisions": alt,
         }
         if world == 1 and not args.no_cpu_baseline:

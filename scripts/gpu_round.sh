@@ -15,6 +15,9 @@ fi
 for P in bf16x3 bf16 fp32; do
   echo "== bench $P"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
 done
+for P in bf16x3 bf16; do
+  echo "== bench $P sequential"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --bands 1 --no-cpu-baseline --no-alt > $O/bench_${P}_seq.json 2> $O/bench_${P}_seq.err; echo "rc=$?"
+done
 if [ -f $R/build/libtangram_hip_alt.so ]; then
 for P in bf16x3 bf16; do
   echo "== bench $P ALT lib"; TANGRAM_AMD_LIB=$R/build/libtangram_hip_alt.so timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/bench_${P}_alt.json 2> $O/bench_${P}_alt.err; echo "rc=$?"
@@ -31,7 +34,7 @@ for f in $O/bench_*.json; do echo $f; python - "$f" <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print({k:d[k] for k in ("value","ms_per_step","roofline","last_main_loss")})
+    print({k:d[k] for k in ("value","ms_per_step","roofline","last_main_loss")}, d.get("kernels_pass"))
     for k in d["kernels"]: print("    %-26s %8.4f ms x%d" % (k["name"],k["avg_ms"],k["launches"]))
 except Exception as e: print("parse fail",e); print(open(sys.argv[1].replace(".json",".err")).read()[-2000:])
 PY

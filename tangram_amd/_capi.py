@@ -24,7 +24,7 @@ X_GENESTAT, X_GNORM2, X_ROWQ, X_ROWPAIR = range(4)
 class TgConfig(ct.Structure):
     _fields_ = [(n, ct.c_int32) for n in
                 ("abi_version", "mode", "precision", "n_cells", "n_genes", "n_spots", "n_spots_total",
-                 "has_density", "has_d_source", "fwd_splits", "tile_size")] + \
+                 "has_density", "has_d_source", "fwd_splits", "tile_size", "pipeline_bands")] + \
                [(n, ct.c_float) for n in
                 ("lambda_g1", "lambda_d", "lambda_g2", "lambda_r", "lambda_l1", "lambda_l2",
                  "lambda_count", "lambda_f_reg", "target_count", "lambda_neighborhood_g1", "lambda_ct_islands")] + \

@@ -23,6 +23,13 @@ static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch,
 static int tg_memset(void* dst, int v, size_t n, tg_stream_t) { memset(dst, v, n); return 0; }
 static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t) { memcpy(dst, src, n); return 0; }
 static int tg_check_launch() { return 0; }
+typedef int tg_event_t;
+static int tg_stream_create(tg_stream_t* s) { *s = nullptr; return 0; }
+static void tg_stream_destroy(tg_stream_t) {}
+static int tg_event_create(tg_event_t* e) { *e = 0; return 0; }
+static void tg_event_destroy(tg_event_t) {}
+static void tg_event_record(tg_event_t, tg_stream_t) {}           // the emulator runs launches synchronously in program order
+static void tg_stream_wait(tg_stream_t, tg_event_t) {}
 #else
 typedef hipStream_t tg_stream_t;
 #define TG_LAUNCH(kern, gx, gy, block, lds, stream, ...) \
@@ -35,6 +42,13 @@ static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t s) {
     return (int)hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
 }
 static int tg_check_launch() { return (int)hipGetLastError(); }
+typedef hipEvent_t tg_event_t;
+static int tg_stream_create(tg_stream_t* s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+static void tg_stream_destroy(tg_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+static int tg_event_create(tg_event_t* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
+static void tg_event_destroy(tg_event_t e) { if (e) (void)hipEventDestroy(e); }
+static void tg_event_record(tg_event_t e, tg_stream_t s) { (void)hipEventRecord(e, s); }
+static void tg_stream_wait(tg_stream_t s, tg_event_t e) { (void)hipStreamWaitEvent(s, e, 0); }
 #endif
 
 // ----------------------------------------------------------------------------------------------
@@ -53,6 +67,7 @@ extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 
 static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+#define TG_MAX_BANDS 16
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
     size_t o_Sk, o_St, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
@@ -60,7 +75,7 @@ struct TgLayout {
         o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[6][3],
         o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
         o_accmpart, o_accm, o_actnorm, total;
-    int T_ct, Tp, has_nb, has_ct, has_ac;
+    int T_ct, Tp, has_nb, has_ct, has_ac, bands;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
@@ -117,6 +132,15 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     const int slots = 256 * (L->T == 256 ? 1 : 2);
     L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots);
     if (L->nsplit > nsteps) L->nsplit = nsteps;
+    // cell-band software pipeline (backward GEMM | streaming Adam | next forward GEMM on three streams): single-GPU Mapper only
+    if (cfg->pipeline_bands < 0 || cfg->pipeline_bands > TG_MAX_BANDS) return tg_fail(TG_ERR_INVALID, "pipeline_bands must be in [0, %d]", TG_MAX_BANDS);
+    L->bands = 1;
+    if (cfg->mode == TG_MODE_MAPPER && L->Vtot == L->V) {
+        if (cfg->pipeline_bands > 1) L->bands = cfg->pipeline_bands;
+        else if (cfg->pipeline_bands == 0 && L->nct >= 32) L->bands = 8;
+        if (L->bands > L->nct) L->bands = L->nct;
+    }
+    if (L->bands > 1) L->nsplit = L->bands;               // one forward partial per cell band
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
     L->o_Sk = take((size_t)L->Cr * L->Kp * L->ESZ);
@@ -206,6 +230,8 @@ struct tg_mapper {
     tg_stream_t stream;
     int64_t step;
     bool ready;
+    tg_stream_t s_adam, s_fwd;                       // library-owned streams of the cell-band pipeline
+    tg_event_t e_bwd[TG_MAX_BANDS], e_adam[TG_MAX_BANDS], e_fwd;
     // profiling
     bool prof;
     std::vector<std::string> prof_names;
@@ -463,6 +489,12 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
     m->step = 0; m->ready = false; m->prof = false;
+    m->s_adam = nullptr; m->s_fwd = nullptr;
+    if (L.bands > 1) {
+        int e = tg_stream_create(&m->s_adam) | tg_stream_create(&m->s_fwd) | tg_event_create(&m->e_fwd);
+        for (int b = 0; b < L.bands; ++b) e |= tg_event_create(&m->e_bwd[b]) | tg_event_create(&m->e_adam[b]);
+        if (e) { delete m; return tg_fail(TG_ERR_HIP, "could not create the pipeline streams / events"); }
+    }
     auto bail = [&](int code) { delete m; return code; };
 
     if (tg_memset(m->ws, 0, L.total, m->stream)) return bail(tg_fail(TG_ERR_HIP, "memset(workspace) failed"));
@@ -507,12 +539,28 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     return TG_OK;
 }
 
-extern "C" void tg_mapper_destroy(tg_mapper* m) { delete m; }
+extern "C" void tg_mapper_destroy(tg_mapper* m) {
+    if (!m) return;
+    if (m->L.bands > 1) {
+        tg_stream_destroy(m->s_adam); tg_stream_destroy(m->s_fwd); tg_event_destroy(m->e_fwd);
+        for (int b = 0; b < m->L.bands; ++b) { tg_event_destroy(m->e_bwd[b]); tg_event_destroy(m->e_adam[b]); }
+    }
+    delete m;
+}
 
 // ---- one iteration ------------------------------------------------------------------------------
+// cell rows / contraction steps of band b
+static void tg_band_range(const TgLayout& L, int b, int* ct0, int* ct1, int* c0, int* c1) {
+    *ct0 = (int)((long long)L.nct * b / L.bands);
+    *ct1 = (int)((long long)L.nct * (b + 1) / L.bands);
+    *c0 = *ct0 * L.T;
+    *c1 = (*ct1 * L.T < L.C) ? *ct1 * L.T : L.C;
+}
+
 template <class PR>
-static int tg_launch_forward(tg_mapper* m) {
+static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int band = -1) {
     const TgLayout& L = m->L;
+    if (band < 0) stream = m->stream;
     TgFwdArgs a;
     a.M = (const float*)(m->st + L.s_M);
     a.rlse2 = m->fp(L.o_rscale);
@@ -520,10 +568,20 @@ static int tg_launch_forward(tg_mapper* m) {
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
     a.nkt = L.nkt; a.nvt = L.nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
-    const int grid = tg_fwd_grid(L.nvt, L.nkt, L.nsplit);
-    if (L.T == 256) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoLarge>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
-    else TG_LAUNCH((tg_fwd_kernel<PR, TgGeoSmall>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
-    tg_prof_mark(m, "tg_fwd_kernel");
+    a.band_index = 0; a.band_step_begin = 0; a.band_step_end = 0;
+    int grid = tg_fwd_grid(L.nvt, L.nkt, L.nsplit);
+    if (band >= 0) {
+        int ct0, ct1, c0, c1;
+        tg_band_range(L, band, &ct0, &ct1, &c0, &c1);
+        a.band_index = band;
+        a.band_step_begin = c0 / PR::BKE;
+        a.band_step_end = (band == L.bands - 1) ? a.nsteps : (ct1 * L.T) / PR::BKE;
+        if (a.band_step_end > a.nsteps) a.band_step_end = a.nsteps;
+        grid = tg_fwd_grid(L.nvt, L.nkt, 1);
+    }
+    if (L.T == 256) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoLarge>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+    else TG_LAUNCH((tg_fwd_kernel<PR, TgGeoSmall>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
+    if (band < 0) tg_prof_mark(m, "tg_fwd_kernel");
     return TG_OK;
 }
 
@@ -574,9 +632,11 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     return TG_OK;
 }
 
+// backward GEMM (X, row-dot partials) over the cell tiles [ct0, ct1) on `stream`
 template <class PR>
-static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
+static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1) {
     const TgLayout& L = m->L;
+    TgBwdArgs a;
     a.dG = m->ws + L.o_dG;
     a.Sk = m->ws + L.o_Sk;
     a.M = (const float*)(m->st + L.s_M); a.X = m->fp(L.o_X);
@@ -586,51 +646,60 @@ static void tg_fill_bwd(tg_mapper* m, TgBwdArgs& a) {
     a.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
     a.part = m->fp(L.o_part);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nsteps = L.Kp / PR::BKE;
+    const int nct = ct1 - ct0;
+    a.ct_offset = ct0;
     // XCD bands along the longer tile axis when it is long enough to feed 8 XCDs, otherwise a plain linear order
-    if (L.nct >= 16 && L.nct >= L.nvt) { a.map = TgTileMap{1, L.nct, L.nvt}; a.map_major_is_cells = 1; }
-    else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, L.nct}; a.map_major_is_cells = 0; }
-    else { a.map = TgTileMap{0, L.nvt, L.nct}; a.map_major_is_cells = 0; }
+    if (nct >= 16 && nct >= L.nvt) { a.map = TgTileMap{1, nct, L.nvt}; a.map_major_is_cells = 1; }
+    else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, nct}; a.map_major_is_cells = 0; }
+    else { a.map = TgTileMap{0, L.nvt, nct}; a.map_major_is_cells = 0; }
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
-}
-
-template <class PR>
-static void tg_launch_bwd(tg_mapper* m, const TgBwdArgs& a) {
-    const TgLayout& L = m->L;
     const int grid = tg_tilemap_grid(a.map);
     if (L.T == 256) {
-        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, m->stream, a);
+        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
     } else {
-        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, m->stream, a);
+        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
     }
+}
+
+static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1) {
+    const TgLayout& L = m->L;
+    TgRowsumArgs r;
+    r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
+    r.c_begin = c0; r.c_end = c1;
+    TG_LAUNCH(tg_rowsum_parts, (c1 - c0 + 255) / 256, 1, 256, 0, stream, r);
+}
+
+static void tg_launch_hist_regs(tg_mapper* m, tg_stream_t stream, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgHistRegArgs h;
+    h.rowq = m->fp(L.o_rowq); h.C = L.C; h.hist = hist_row ? hist_row : m->fp(L.o_scal);
+    h.lambda_r = m->cfg.lambda_r; h.lambda_l1 = m->cfg.lambda_l1; h.lambda_l2 = m->cfg.lambda_l2;
+    h.constrained = (m->cfg.mode == TG_MODE_CONSTRAINED);
+    TG_LAUNCH(tg_hist_regs, 1, 1, 1024, 64, stream, h);
 }
 
 template <class PR>
 static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
-    TgBwdArgs a;
-    tg_fill_bwd<PR>(m, a);
-    tg_launch_bwd<PR>(m, a);
+    tg_launch_bwd<PR>(m, m->stream, 0, L.nct);
     tg_prof_mark(m, "tg_bwd_kernel");
-    TgRowsumArgs r;
-    r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
-    TG_LAUNCH(tg_rowsum_parts, (L.C + 255) / 256, 1, 256, 0, m->stream, r);
+    tg_launch_rowsum(m, m->stream, 0, L.C);
     tg_prof_mark(m, "tg_rowsum_parts");
     if (L.full) {
-        TgHistRegArgs h;
-        h.rowq = m->fp(L.o_rowq); h.C = L.C; h.hist = hist_row ? hist_row : m->fp(L.o_scal);
-        h.lambda_r = m->cfg.lambda_r; h.lambda_l1 = m->cfg.lambda_l1; h.lambda_l2 = m->cfg.lambda_l2;
-        h.constrained = (m->cfg.mode == TG_MODE_CONSTRAINED);
-        TG_LAUNCH(tg_hist_regs, 1, 1, 1024, 64, m->stream, h);
+        tg_launch_hist_regs(m, m->stream, hist_row);
         tg_prof_mark(m, "tg_hist_regs");
     }
     return TG_OK;
 }
 
-// streaming softmax-backward + Adam; `finalize`: write the next softmax statistics directly (single GPU, no filter)
-static int tg_launch_update(tg_mapper* m, float lr, bool finalize) {
+// streaming softmax-backward + Adam over the cells [c0, c1); `finalize`: write the next softmax statistics directly
+// (single GPU, no filter)
+static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t stream = nullptr, int c0 = 0, int c1 = -1) {
     const TgLayout& L = m->L;
+    const bool whole = c1 < 0;
+    if (whole) { stream = m->stream; c0 = 0; c1 = L.C; }
     TgUpdateArgs u;
     u.X = m->fp(L.o_X);
     u.M = (float*)(m->st + L.s_M); u.am = (float*)(m->st + L.s_m1); u.av = (float*)(m->st + L.s_m2);
@@ -640,15 +709,15 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize) {
     u.vcoef = m->fp(L.o_vcoef); u.r = m->fp(L.o_rowq);
     u.pair_out = m->fp(L.o_rowpair);
     u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_scale = m->fp(L.o_rscale);
-    u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0;
+    u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0; u.c_begin = c0;
     u.lambda_r = m->cfg.lambda_r; u.lambda_l1 = m->cfg.lambda_l1; u.lambda_l2 = m->cfg.lambda_l2;
     const double t = (double)(m->step + 1);
     u.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
     u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
     u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
-    if (L.full) TG_LAUNCH((tg_adam_update<true>), L.C, 1, 256, 64, m->stream, u);
-    else TG_LAUNCH((tg_adam_update<false>), L.C, 1, 256, 64, m->stream, u);
-    tg_prof_mark(m, "tg_adam_update");
+    if (L.full) TG_LAUNCH((tg_adam_update<true>), c1 - c0, 1, 256, 64, stream, u);
+    else TG_LAUNCH((tg_adam_update<false>), c1 - c0, 1, 256, 64, stream, u);
+    if (whole) tg_prof_mark(m, "tg_adam_update");
     return TG_OK;
 }
 
@@ -670,7 +739,51 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     return TG_OK;
 }
 
-static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row) {
+// One iteration as a software pipeline over bands of cells on three streams:
+//   caller's stream : [forward of this step unless pre-launched] -> loss kernels -> backward GEMM(band 0), (band 1), ...
+//   s_adam          : for each band, as soon as its backward is done: row sums -> streaming softmax-backward + Adam
+//   s_fwd           : for each band, as soon as its rows are updated: forward GEMM partial of the NEXT step
+// The HBM-bound update of band b runs beside the matrix-core-bound GEMMs of the neighbouring bands.  Every
+// dependency is a HIP event; nothing is reordered that the sequential schedule orders (same arithmetic, same results).
+template <class PR>
+static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool fwd_prelaunched, bool prelaunch_next) {
+    const TgLayout& L = m->L;
+    int rc;
+    if (fwd_prelaunched) tg_stream_wait(m->stream, m->e_fwd);
+    else if ((rc = tg_launch_forward<PR>(m))) return rc;
+    if ((rc = tg_launch_ghat_stats(m))) return rc;
+    if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
+    for (int b = 0; b < L.bands; ++b) {
+        int ct0, ct1, c0, c1;
+        tg_band_range(L, b, &ct0, &ct1, &c0, &c1);
+        tg_launch_bwd<PR>(m, m->stream, ct0, ct1);
+        tg_event_record(m->e_bwd[b], m->stream);
+        tg_stream_wait(m->s_adam, m->e_bwd[b]);
+        tg_launch_rowsum(m, m->s_adam, c0, c1);
+        if ((rc = tg_launch_update(m, lr, true, m->s_adam, c0, c1))) return rc;
+        tg_event_record(m->e_adam[b], m->s_adam);
+        if (prelaunch_next) {
+            tg_stream_wait(m->s_fwd, m->e_adam[b]);
+            if ((rc = tg_launch_forward<PR>(m, m->s_fwd, b))) return rc;
+        }
+    }
+    if (L.full) tg_launch_hist_regs(m, m->s_adam, hist_row);          // needs the row sums of every band
+    tg_event_record(m->e_adam[L.bands - 1], m->s_adam);
+    if (prelaunch_next) tg_event_record(m->e_fwd, m->s_fwd);
+    tg_stream_wait(m->stream, m->e_adam[L.bands - 1]);               // join: the caller's stream sees the updated state
+    m->step += 1;
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
+static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row, bool prelaunched = false, bool prelaunch_next = false) {
+    if (m->L.bands > 1 && !m->prof) {
+        switch (m->cfg.precision) {
+            case TG_PREC_F32: return tg_one_step_pipelined<PrecF32>(m, lr, hist_row, prelaunched, prelaunch_next);
+            case TG_PREC_BF16: return tg_one_step_pipelined<PrecBF16>(m, lr, hist_row, prelaunched, prelaunch_next);
+            default: return tg_one_step_pipelined<PrecBF16x3>(m, lr, hist_row, prelaunched, prelaunch_next);
+        }
+    }
     switch (m->cfg.precision) {
         case TG_PREC_F32: return tg_one_step<PrecF32>(m, lr, hist_row);
         case TG_PREC_BF16: return tg_one_step<PrecBF16>(m, lr, hist_row);
@@ -681,10 +794,14 @@ static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row) {
 extern "C" int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (n_steps < 0) return tg_fail(TG_ERR_INVALID, "n_steps < 0");
+    const bool pipelined = m->L.bands > 1 && !m->prof;
+    bool prelaunched = false;
     for (int i = 0; i < n_steps; ++i) {
         float* row = history_dev ? history_dev + (size_t)(first_row + i) * TG_H_NTERMS : nullptr;
-        int rc = tg_dispatch_step(m, lr, row);
+        const bool next = pipelined && (i + 1 < n_steps);        // the last step of a call leaves nothing in flight
+        int rc = tg_dispatch_step(m, lr, row, prelaunched, next);
         if (rc) return rc;
+        prelaunched = next;
     }
     return TG_OK;
 }

@@ -173,6 +173,7 @@ struct TgFwdArgs {
     int nkt;                 // gene tiles (Kp / TN)
     int nvt, nsplit;         // spot tiles, cell-range splits
     int nsteps;              // Cp / BKE
+    int band_index, band_step_begin, band_step_end;   // band mode (band_step_end > 0): ONE cell range -> partial `band_index`
 };
 // grid of the forward kernel: the nkt gene tiles that share one M panel (same spot tile, same cell range) sit
 // next to each other on ONE XCD; the panels in flight on an XCD belong to the same cell range and share S^T.
@@ -193,11 +194,13 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
     int vt, kt, split;
-    if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, a.nsplit, vt, kt, split)) return;
+    const bool band = a.band_step_end > 0;
+    if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, band ? 1 : a.nsplit, vt, kt, split)) return;
     const int nsplit = a.nsplit;
     const int v0 = vt * GE::TM, k0 = kt * GE::TN;
-    const int s_begin = (int)(((long long)a.nsteps * split) / nsplit);
-    const int s_end = (int)(((long long)a.nsteps * (split + 1)) / nsplit);
+    if (band) split = a.band_index;
+    const int s_begin = band ? a.band_step_begin : (int)(((long long)a.nsteps * split) / nsplit);
+    const int s_end = band ? a.band_step_end : (int)(((long long)a.nsteps * (split + 1)) / nsplit);
 
     f32x4 acc[GE::FM][GE::FN];
 #pragma unroll
@@ -569,6 +572,7 @@ struct TgBwdArgs {
     int C, V, Vp, Vr, Kp, nsteps;
     TgTileMap map;                                 // major/minor = (cell tile, spot tile) or swapped
     int map_major_is_cells;
+    int ct_offset;                                 // first cell tile of this launch (cell-band pipelining)
     float lambda_r, lambda_l1, lambda_l2;
 };
 enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
@@ -582,7 +586,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     const int wm = wave / GE::WN, wn = wave % GE::WN;
     int t_major, t_minor;
     if (!tg_tilemap(a.map, blockIdx.x, t_major, t_minor)) return;
-    const int vt = a.map_major_is_cells ? t_minor : t_major, ct = a.map_major_is_cells ? t_major : t_minor;
+    const int vt = a.map_major_is_cells ? t_minor : t_major, ct = a.ct_offset + (a.map_major_is_cells ? t_major : t_minor);
     const int v0 = vt * GE::TM, c0 = ct * GE::TN;
     const int nsteps = a.nsteps;
 
@@ -1041,6 +1045,7 @@ struct TgUpdateArgs {
     float* pair_out;                                  // [2][C] (max, Z) of the new row (cross-GPU exchange)
     float* new_shift; float* new_invz; float* new_scale;   // finalised statistics (single GPU) or null
     int C, V, Vp, Vr, finalize;
+    int c_begin;                                      // first cell of this launch (grid = number of cells)
     float lambda_r, lambda_l1, lambda_l2;
     float step_size, bc2_sqrt, beta1, beta2, eps;
 };
@@ -1049,7 +1054,7 @@ template <bool FULL>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [4 waves][2]
-    const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float sh = a.rshift[c], iz = a.rinvz[c], rc = a.r[c];
     const float fg = a.fgate ? a.fgate[c] : 1.f;
     const float wc = a.dens_w ? a.dens_w[c] : 1.f;
@@ -1124,10 +1129,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
 struct TgRowsumArgs {
     const float* part; int nvt; int C; int np;
     float* rowq;               // [np][C] summed partials (row 0 = r_c)
+    int c_begin, c_end;        // cells handled by this launch
 };
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= a.C) return;
+    const int c = a.c_begin + blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.c_end) return;
     for (int q = 0; q < a.np; ++q) {
         float s = 0.f;
         for (int p = 0; p < a.nvt; ++p) s += a.part[((size_t)p * a.np + q) * a.C + c];

@@ -137,3 +137,26 @@ def test_full_size_properties_cfg2():
     P2 = torch.softmax(M[:, :V], dim=1)
     assert float((e.result() - P2).abs().max()) < 1e-6
     assert step == n + 1
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_pipelined_schedule_matches_sequential(precision):
+    """3-stream cell-band pipeline (backward | Adam | next forward overlap) vs the one-stream schedule on real hardware:
+    any missing event dependency shows up here as a difference."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    C, K, V = 5000, 100, 1500
+    data = orc.make_synthetic(C, K, V, seed=31)
+    M0 = orc.reference_init_M(C, V, 8)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_r=1e-3)
+    outs = []
+    for bands in (1, 5, 5):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision=precision, lambdas=lam,
+                            pipeline_bands=bands)
+        hist = e.new_history(30)
+        e.step(17, 0.1, hist, 0)
+        e.step(13, 0.1, hist, 17)
+        outs.append((e.result().cpu().numpy(), hist.cpu().numpy()))
+    assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1][:, :5], outs[2][1][:, :5]), "pipelined runs must be bit-reproducible"
+    np.testing.assert_allclose(outs[0][1][:, :5], outs[1][1][:, :5], atol=5e-6 if precision != "bf16" else 1e-4)
+    assert np.abs(outs[0][0] - outs[1][0]).max() < (1e-4 if precision != "bf16" else 5e-3)

@@ -75,3 +75,29 @@ def test_emulated_large_tile_geometry(sim, precision):
         scale = max(1.0, abs(ho[k][0]))
         np.testing.assert_allclose(hist[:, col].numpy(), np.array(ho[k]), atol=tol["loss"] * scale, rtol=0, err_msg=k)
     assert np.abs(e.result().numpy() - Po).max() < tol["P"]
+
+
+@pytest.mark.parametrize("bands,tile", [(3, 128), (2, 256)])
+def test_emulated_cell_band_pipeline(sim, bands, tile):
+    """The 3-stream cell-band schedule (backward | Adam | next forward) must give the sequential schedule's results."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V = 420, 24, 150
+    data = orc.make_synthetic(C, K, V, seed=13)
+    M0 = orc.reference_init_M(C, V, 6)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.4, lambda_r=1e-3)
+    outs = []
+    for pb in (1, bands):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam,
+                            tile_size=tile, pipeline_bands=pb)
+        hist = e.new_history(4)
+        e.step(3, 0.1, hist, 0)          # three steps in one call: steps 2 and 3 use the pre-launched forward
+        e.step(1, 0.1, hist, 3)
+        outs.append((e.result().numpy(), hist.numpy()))
+    np.testing.assert_allclose(outs[0][1][:, :5], outs[1][1][:, :5], atol=2e-6, rtol=1e-6)
+    # (the forward partial sums are cut at band boundaries instead of equal step ranges: fp32 summation order differs)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], atol=2e-5)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(4, 0.1)
+    np.testing.assert_allclose(outs[1][1][:, 0], np.array(ho["total_loss"]), atol=1e-5)
+    assert np.abs(outs[1][0] - Po).max() < 2e-5
