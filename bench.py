@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the short runs of the other GEMM precisions")
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile edge (128 or 256); 0 = automatic")
-    ap.add_argument("--bands", type=int, default=0, help="cell bands of the 3-stream pipeline (0 = automatic, 1 = sequential schedule)")
+    ap.add_argument("--bands", type=int, default=0, help="cell bands of the opt-in 3-stream pipeline (0/1 = sequential schedule, the default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,7 +142,7 @@ def main():
     run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    run(args.steps)                                 # timed region: the product schedule (3-stream cell-band pipeline on 1 GPU)
+    run(args.steps)                                 # timed region: the product schedule
     fence()
     elapsed = time.perf_counter() - t0
     # per-kernel durations: HIP events after every kernel on the kernel's stream.  Event-bracketing needs the kernels on

@@ -63,7 +63,7 @@ typedef struct tg_config {
     int32_t has_d_source;    /* d_source given (:118) */
     int32_t fwd_splits;      /* 0 = choose automatically; >0 = number of cell-range splits of the forward GEMM */
     int32_t tile_size;       /* 0 = choose automatically; 128 or 256 = GEMM output tile edge (tuning / tests)        */
-    int32_t pipeline_bands;  /* 0 = automatic; 1 = sequential schedule; 2..16 = cell bands of the 3-stream pipeline   */
+    int32_t pipeline_bands;  /* 0/1 = sequential schedule (default); 2..16 = cell bands of the opt-in 3-stream pipeline */
     float lambda_g1, lambda_d, lambda_g2, lambda_r, lambda_l1, lambda_l2;
     float lambda_count, lambda_f_reg, target_count;     /* constrained mode (:426-428, :480-483) */
     float lambda_neighborhood_g1;                       /* spatially weighted gene term (:33, :234-239); needs W, W^T */

@@ -15,9 +15,6 @@ fi
 for P in bf16x3 bf16 fp32; do
   echo "== bench $P"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/bench_$P.json 2> $O/bench_$P.err; echo "rc=$?"
 done
-for P in bf16x3 bf16; do
-  echo "== bench $P sequential"; timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --bands 1 --no-cpu-baseline --no-alt > $O/bench_${P}_seq.json 2> $O/bench_${P}_seq.err; echo "rc=$?"
-done
 if [ -f $R/build/libtangram_hip_alt.so ]; then
 for P in bf16x3 bf16; do
   echo "== bench $P ALT lib"; TANGRAM_AMD_LIB=$R/build/libtangram_hip_alt.so timeout 900 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/bench_${P}_alt.json 2> $O/bench_${P}_alt.err; echo "rc=$?"

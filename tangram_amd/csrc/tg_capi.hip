@@ -132,12 +132,13 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     const int slots = 256 * (L->T == 256 ? 1 : 2);
     L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots);
     if (L->nsplit > nsteps) L->nsplit = nsteps;
-    // cell-band software pipeline (backward GEMM | streaming Adam | next forward GEMM on three streams): single-GPU Mapper only
+    // cell-band software pipeline (backward GEMM | streaming Adam | next forward GEMM on three streams): single-GPU Mapper only.
+    // Opt-in (pipeline_bands >= 2): measured SLOWER than the sequential schedule on MI355X (profiles/r01/run14): the 256^2 GEMM
+    // workgroups fill the VGPR file of their CU, so the streaming kernel cannot co-reside and only takes CUs away from the GEMMs.
     if (cfg->pipeline_bands < 0 || cfg->pipeline_bands > TG_MAX_BANDS) return tg_fail(TG_ERR_INVALID, "pipeline_bands must be in [0, %d]", TG_MAX_BANDS);
     L->bands = 1;
     if (cfg->mode == TG_MODE_MAPPER && L->Vtot == L->V) {
         if (cfg->pipeline_bands > 1) L->bands = cfg->pipeline_bands;
-        else if (cfg->pipeline_bands == 0 && L->nct >= 32) L->bands = 8;
         if (L->bands > L->nct) L->bands = L->nct;
     }
     if (L->bands > 1) L->nsplit = L->bands;               // one forward partial per cell band

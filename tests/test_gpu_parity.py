@@ -158,5 +158,5 @@ def test_pipelined_schedule_matches_sequential(precision):
         e.step(13, 0.1, hist, 17)
         outs.append((e.result().cpu().numpy(), hist.cpu().numpy()))
     assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1][:, :5], outs[2][1][:, :5]), "pipelined runs must be bit-reproducible"
-    np.testing.assert_allclose(outs[0][1][:, :5], outs[1][1][:, :5], atol=5e-6 if precision != "bf16" else 1e-4)
+    np.testing.assert_allclose(outs[0][1][:, :5], outs[1][1][:, :5], atol=5e-6 if precision != "bf16" else 1e-4, rtol=1e-6)
     assert np.abs(outs[0][0] - outs[1][0]).max() < (1e-4 if precision != "bf16" else 5e-3)
