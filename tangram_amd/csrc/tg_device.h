@@ -177,4 +177,6 @@ TG_DEV void tg_store_operand_chunk(unsigned char* row_base, int step, int kc, co
 
 // XOR swizzle of the 16-byte chunk index inside a 128-byte LDS tile row: ds_read_b128 of 16
 // consecutive rows at one logical chunk touches all 16 slots of the two 256-byte bank rows.
-TG_DEV int tg_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// The extra (row >> 4) & 1 term is constant inside a 16-row fragment (reads unaffected) and makes the forward
+// kernel's transposed ds_write_b128 (rows 4q + i of 8 consecutive lanes) conflict-free as well.
+TG_DEV int tg_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 7) ^ ((row >> 4) & 1)); }

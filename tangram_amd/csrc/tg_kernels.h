@@ -66,20 +66,20 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
     const int r = lane & 15, g = lane >> 4;
     const u32x4* sa = st + (wm * (GE::TM / GE::WM) + r) * 8;  // this lane's first A row
     const u32x4* sb = st + GE::A_CHUNKS + (wn * (GE::TN / GE::WN) + r) * 8;
-    const int swr = (((wm * (GE::TM / GE::WM) + r) >> 1) & 7), swb = (((wn * (GE::TN / GE::WN) + r) >> 1) & 7);
-    // rows of successive fragments differ by 16, which leaves (row >> 1) & 7 unchanged: one swizzle per lane
+    // rows of successive fragments differ by 16: (row >> 1) & 7 is the same for all of them, (row >> 4) & 1 alternates
+    const int swr = tg_swz(wm * (GE::TM / GE::WM) + r, 0), swb = tg_swz(wn * (GE::TN / GE::WN) + r, 0);
     u32x4 a[2][GA][PR::NP], b[2][GE::FN][PR::NP];
     auto load_a = [&](int buf, int q, int blk) {
 #pragma unroll
         for (int f = 0; f < GA; ++f)
 #pragma unroll
-            for (int p = 0; p < PR::NP; ++p) a[buf][f][p] = sa[(blk * GA + f) * 128 + ((4 * (q + p) + g) ^ swr)];
+            for (int p = 0; p < PR::NP; ++p) a[buf][f][p] = sa[(blk * GA + f) * 128 + ((4 * (q + p) + g) ^ swr ^ ((blk * GA + f) & 1))];
     };
     auto load_b = [&](int buf, int q) {
 #pragma unroll
         for (int f = 0; f < GE::FN; ++f)
 #pragma unroll
-            for (int p = 0; p < PR::NP; ++p) b[buf][f][p] = sb[f * 128 + ((4 * (q + p) + g) ^ swb)];
+            for (int p = 0; p < PR::NP; ++p) b[buf][f][p] = sb[f * 128 + ((4 * (q + p) + g) ^ swb ^ (f & 1))];
     };
     load_b(0, 0);
     load_a(0, 0, 0);
@@ -130,7 +130,7 @@ TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_by
 #pragma unroll
     for (int i = 0; i < ROWS * 8 / NT; ++i) {
         const int idx = t + i * NT, row = idx >> 3;
-        const int logical = (idx & 7) ^ ((row >> 1) & 7);
+        const int logical = tg_swz(row, idx & 7);                 // involution: logical = physical ^ s(row)
         tg_glds16(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
     }
 }
@@ -208,9 +208,14 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < GE::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // A staging: thread = (spot quad, chunk slot of the 128-byte step row)
+    // A staging: thread = (spot quad, slot).  One slot = RS cells x 4 spots loaded as RS float4 rows of M.
+    //   bf16 / fp32 : slot = one 16-byte chunk (CH cells);
+    //   bf16x3      : slot = HALF a k-chunk (4 cells): the thread writes 8 bytes of the hi chunk and 8 bytes of the lo chunk,
+    //                 so that every exponential is evaluated exactly once.
+    constexpr int RS = (PR::NP == 2) ? PR::CH / 2 : PR::CH;
     const int quad = t % (GE::TM / 4), slot = t / (GE::TM / 4);
-    const int kc = (PR::NP == 2) ? (slot & 3) : slot;          // k-chunk whose cells this thread exponentiates
+    const int kc = (PR::NP == 2) ? (slot >> 1) : slot;         // k-chunk of the 128-byte step row
+    const int half = (PR::NP == 2) ? (slot & 1) : 0;
     const int vcol = v0 + 4 * quad;
     const int vload = (vcol < a.Vp) ? vcol : 0;
     bool vok[4];
@@ -218,15 +223,15 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     for (int i = 0; i < 4; ++i) vok[i] = (vcol + i) < a.V;
     const bool full_tile = (v0 + GE::TM) <= a.V;               // wave-uniform: interior tiles skip the per-element selects
 
-    f32x4 mreg[PR::CH];
-    float sh[PR::CH];
+    f32x4 mreg[RS];
+    float sh[RS];
     TgKTile<GE::TN, GE::NT> breg;
     const size_t bpitch = (size_t)a.nsteps * 128;
 
     auto load_stage = [&](int step) {
-        const int cb = step * PR::BKE + kc * PR::CH;
+        const int cb = step * PR::BKE + kc * PR::CH + half * RS;
 #pragma unroll
-        for (int j = 0; j < PR::CH; ++j) {
+        for (int j = 0; j < RS; ++j) {
             const int c = cb + j;
             const int cc = c < a.C ? c : a.C - 1;
             mreg[j] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + vload);
@@ -237,16 +242,26 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     auto store_stage = [&](u32x4* st) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float x[PR::CH];
+            float x[RS];
 #pragma unroll
-            for (int j = 0; j < PR::CH; ++j) {
+            for (int j = 0; j < RS; ++j) {
                 const float p = tg_exp2(fmaf(mreg[j][i], TG_LOG2E, -sh[j]));
                 x[j] = (full_tile || vok[i]) ? p : 0.f;
             }
-            u32x4 hi, lo;
-            PR::cvt(x, hi, lo);
             const int row = 4 * quad + i;
-            st[row * 8 + tg_swz(row, slot)] = (PR::NP == 2 && slot >= 4) ? lo : hi;
+            if constexpr (PR::NP == 2) {
+                const unsigned h0 = tg_pack_bf16(x[0], x[1]), h1 = tg_pack_bf16(x[2], x[3]);
+                const unsigned l0 = tg_pack_bf16(x[0] - tg_bf16_lo_to_f32(h0), x[1] - tg_bf16_hi_to_f32(h0));
+                const unsigned l1 = tg_pack_bf16(x[2] - tg_bf16_lo_to_f32(h1), x[3] - tg_bf16_hi_to_f32(h1));
+                u32x2* hp = (u32x2*)(st + row * 8 + tg_swz(row, kc));
+                u32x2* lp = (u32x2*)(st + row * 8 + tg_swz(row, 4 + kc));
+                hp[half] = u32x2{h0, h1};
+                lp[half] = u32x2{l0, l1};
+            } else {
+                u32x4 hi, lo;
+                PR::cvt(x, hi, lo);
+                st[row * 8 + tg_swz(row, slot)] = hi;
+            }
         }
         if (!TG_GLDS) breg.store(st + GE::A_CHUNKS, t);
     };
