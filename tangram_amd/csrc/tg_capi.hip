@@ -640,7 +640,7 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1) {
     TgBwdArgs a;
     a.dG = m->ws + L.o_dG;
     a.Sk = m->ws + L.o_Sk;
-    a.M = (const float*)(m->st + L.s_M); a.X = m->fp(L.o_X);
+    a.M = (const float*)(m->st + L.s_M); a.X = (void*)m->fp(L.o_X);
     a.rshift = m->fp(L.o_rshift); a.rinvz = m->fp(L.o_rinvz);
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     a.vcoef = m->fp(L.o_vcoef);
@@ -716,8 +716,9 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     u.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
     u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
     u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
-    if (L.full) TG_LAUNCH((tg_adam_update<true>), c1 - c0, 1, 256, 64, stream, u);
-    else TG_LAUNCH((tg_adam_update<false>), c1 - c0, 1, 256, 64, stream, u);
+    const bool x16 = (m->cfg.precision == TG_PREC_BF16);     // PrecBF16::X16
+    if (L.full) { if (x16) TG_LAUNCH((tg_adam_update<true, true>), c1 - c0, 1, 256, 64, stream, u); else TG_LAUNCH((tg_adam_update<true, false>), c1 - c0, 1, 256, 64, stream, u); }
+    else { if (x16) TG_LAUNCH((tg_adam_update<false, true>), c1 - c0, 1, 256, 64, stream, u); else TG_LAUNCH((tg_adam_update<false, false>), c1 - c0, 1, 256, 64, stream, u); }
     if (whole) tg_prof_mark(m, "tg_adam_update");
     return TG_OK;
 }

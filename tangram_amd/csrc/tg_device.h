@@ -26,6 +26,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define gridDim (hipsim::M().gridDim)
 #define TG_LDS_DECL unsigned char* tg_lds = hipsim::M().lds
 #define TG_SCHED_FENCE() ((void)0)
+#define TG_SETPRIO(n) ((void)0)
 #define __syncthreads() hipsim::block_barrier()
 TG_DEV float tg_exp(float x) { return expf(x); }
 TG_DEV float tg_log(float x) { return logf(x); }
@@ -66,6 +67,11 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
 #define TG_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char tg_lds[]
 // pins the instruction order at this point (the machine scheduler otherwise sinks ds_reads next to their first use)
 #define TG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef TG_EXP_SETPRIO
+#define TG_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define TG_SETPRIO(n) ((void)0)
+#endif
 typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
 TG_DEV float tg_exp(float x) { return __expf(x); }
@@ -119,6 +125,7 @@ TG_DEV float tg_fmax(float a, float b) { return a > b ? a : b; }
 //   KQ = k-chunk groups per step a lane walks through, NP = parts (hi, lo) per fragment.
 // ----------------------------------------------------------------------------------------------
 struct PrecF32 {
+    static constexpr bool X16 = false;      // backward product X kept in fp32
     static constexpr int kId = 0, KQ = 2, NP = 1, CH = 4, BKE = 32, ESZ = 4, KCH = 8;
     TG_DEVM static void cvt(const float (&x)[4], u32x4& hi, u32x4& lo) {
         hi = u32x4{__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
@@ -136,6 +143,7 @@ struct PrecF32 {
 };
 
 struct PrecBF16 {
+    static constexpr bool X16 = true;       // X = S dGhat^T is built from bf16 operands: keeping it in bf16 adds no new error class
     static constexpr int kId = 1, KQ = 2, NP = 1, CH = 8, BKE = 64, ESZ = 2, KCH = 8;
     TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
         hi = u32x4{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3]), tg_pack_bf16(x[4], x[5]), tg_pack_bf16(x[6], x[7])};
@@ -145,6 +153,7 @@ struct PrecBF16 {
 };
 
 struct PrecBF16x3 {
+    static constexpr bool X16 = false;
     static constexpr int kId = 2, KQ = 1, NP = 2, CH = 8, BKE = 32, ESZ = 4, KCH = 4;   // ESZ: bytes per element incl. lo
     TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
         float r[8];

@@ -60,7 +60,11 @@ typedef TgGeo<256, 256, 2, 4> TgGeoLarge;
 // covered by matrix work inside the wave (the compiler then waits with a partial lgkmcnt instead of lgkmcnt(0)).
 template <class PR, class GE, int GA_ = 0>
 TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[GE::FM][GE::FN]) {
+#ifdef TG_EXP_GA
+    constexpr int GA = GA_ ? GA_ : TG_EXP_GA;
+#else
     constexpr int GA = GA_ ? GA_ : ((PR::NP == 2) ? 2 : 4);   // A fragments per block (register budget)
+#endif
     constexpr int NB = GE::FM / GA;                           // blocks per k-chunk group
     constexpr int NG = PR::KQ * NB;                           // pipeline length
     const int r = lane & 15, g = lane >> 4;
@@ -92,11 +96,13 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
             load_a((i + 1) & 1, qn, bn);
         }
         TG_SCHED_FENCE();                                     // next block's LDS reads stay ahead of this block's MFMAs
+        TG_SETPRIO(1);
 #pragma unroll
         for (int fi = 0; fi < GA; ++fi)
 #pragma unroll
             for (int fj = 0; fj < GE::FN; ++fj)
                 acc[blk * GA + fi][fj] = PR::mma(a[i & 1][fi], b[q & 1][fj], acc[blk * GA + fi][fj]);
+        TG_SETPRIO(0);
         TG_SCHED_FENCE();
     }
 }
@@ -578,7 +584,7 @@ struct TgBwdArgs {
     const unsigned char* dG;      // A operand [Vr][nsteps][128 B]
     const unsigned char* Sk;      // B operand [Cr][nsteps][128 B]
     const float* M;                                // logits, pitch Vp
-    float* X;                                      // [C][Vp] backward GEMM result S dGhat^T (consumed by tg_adam_update)
+    void* X;                                       // [C][Vp] backward GEMM result S dGhat^T (fp32, or bf16 when PR::X16) for tg_adam_update
     const float* rshift; const float* rinvz;       // [Cp] softmax shift and 1/Z of the CURRENT M
     const float* fgate;                            // [C] filter f_c (constrained) or null
     const float* vcoef;                            // a_v at [2*Vr + v]
@@ -683,7 +689,13 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
 #pragma unroll
                 for (int f = 0; f < EB; ++f) {
                     const int fi = fb + f, v = vbase + fi * 16;
-                    if (cok && v < a.Vp) *(f32x4*)(a.X + (size_t)cc * a.Vp + v) = acc[fi][fj];   // X = S dGhat^T, kept for the update
+                    if (cok && v < a.Vp) {                                                        // X = S dGhat^T, kept for the update
+                        if constexpr (PR::X16)
+                            *(u32x2*)((unsigned short*)a.X + (size_t)cc * a.Vp + v) =
+                                u32x2{tg_pack_bf16(acc[fi][fj][0], acc[fi][fj][1]), tg_pack_bf16(acc[fi][fj][2], acc[fi][fj][3])};
+                        else
+                            *(f32x4*)((float*)a.X + (size_t)cc * a.Vp + v) = acc[fi][fj];
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (cok && (v + e) < a.V) {
@@ -1052,7 +1064,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ac_grad(TgAcArgs a) {
 //   reads X, M, m, v (16 B / element), writes M, m, v (12 B / element); algorithmic traffic 24 B / element.
 // ----------------------------------------------------------------------------------------------
 struct TgUpdateArgs {
-    const float* X; float* M; float* am; float* av;   // [C][Vp]
+    const void* X; float* M; float* am; float* av;    // [C][Vp] (X fp32, or bf16 when X16)
     const float* rshift; const float* rinvz;          // softmax statistics of the CURRENT M
     const float* fgate; const float* dens_w;          // [C] or null
     const float* vcoef;                               // a_v at [2*Vr + v]
@@ -1065,7 +1077,7 @@ struct TgUpdateArgs {
     float step_size, bc2_sqrt, beta1, beta2, eps;
 };
 
-template <bool FULL>
+template <bool FULL, bool X16>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [4 waves][2]
@@ -1077,7 +1089,13 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     const size_t row = (size_t)c * a.Vp;
     float lmax = TG_NEG_BIG, lsum = 0.f;
     for (int v = 4 * t; v < a.V; v += 1024) {
-        const f32x4 xq = *(const f32x4*)(a.X + row + v);
+        f32x4 xq;
+        if constexpr (X16) {
+            const u32x2 xp = *(const u32x2*)((const unsigned short*)a.X + row + v);
+            xq = f32x4{tg_bf16_lo_to_f32(xp[0]), tg_bf16_hi_to_f32(xp[0]), tg_bf16_lo_to_f32(xp[1]), tg_bf16_hi_to_f32(xp[1])};
+        } else {
+            xq = *(const f32x4*)((const float*)a.X + row + v);
+        }
         f32x4 mq = *(const f32x4*)(a.M + row + v);
         f32x4 m1 = *(const f32x4*)(a.am + row + v);
         f32x4 m2 = *(const f32x4*)(a.av + row + v);
