@@ -26,12 +26,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define gridDim (hipsim::M().gridDim)
 #define TG_LDS_DECL unsigned char* tg_lds = hipsim::M().lds
 #define TG_SCHED_FENCE() ((void)0)
-#define TG_SETPRIO(n) ((void)0)
 #define __syncthreads() hipsim::block_barrier()
 TG_DEV float tg_exp(float x) { return expf(x); }
 TG_DEV float tg_log(float x) { return logf(x); }
 TG_DEV float tg_exp2(float x) { return exp2f(x); }
-TG_DEV float tg_rcp(float x) { return 1.0f / x; }
 TG_DEV float tg_shfl_xor(float v, int mask) { return hipsim::shfl_idx(v, hipsim::lane_id() ^ mask); }
 TG_DEV int tg_lane() { return hipsim::lane_id(); }
 TG_DEV int tg_uniform(int x) { return x; }
@@ -48,7 +46,6 @@ TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) {
     hipsim::mfma16_f32(a, b, t);
     return f32x4{t[0], t[1], t[2], t[3]};
 }
-TG_DEV float tg_atomic_add(float* p, float v) { float o = *p; *p = o + v; return o; }
 // global -> LDS DMA of 16 bytes per lane: LDS destination = wave-uniform base + lane * 16
 TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
     memcpy(lds_wave_base + 16 * hipsim::lane_id(), src, 16);
@@ -67,17 +64,11 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
 #define TG_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char tg_lds[]
 // pins the instruction order at this point (the machine scheduler otherwise sinks ds_reads next to their first use)
 #define TG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifdef TG_EXP_SETPRIO
-#define TG_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define TG_SETPRIO(n) ((void)0)
-#endif
 typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tg_bf16x2 __attribute__((ext_vector_type(2)));
 TG_DEV float tg_exp(float x) { return __expf(x); }
 TG_DEV float tg_log(float x) { return __logf(x); }
 TG_DEV float tg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
-TG_DEV float tg_rcp(float x) { return __frcp_rn(x); }
 TG_DEV float tg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 TG_DEV int tg_lane() { return threadIdx.x & 63; }
 TG_DEV int tg_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -93,7 +84,6 @@ TG_DEV f32x4 tg_mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 }
 // v_mfma_f32_16x16x4_f32: lane l holds A[row=l&15][k=l>>4], B[k=l>>4][col=l&15]; exact f32 fmaf chain.
 TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-TG_DEV float tg_atomic_add(float* p, float v) { return atomicAdd(p, v); }
 // global_load_lds_dwordx4: asynchronous global -> LDS copy that bypasses the VGPRs; the LDS destination is
 // M0 (wave-uniform base) + lane * 16, the global source address is per lane.  Completion is tracked by vmcnt;
 // hipcc drains it before the next __syncthreads().

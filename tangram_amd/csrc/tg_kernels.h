@@ -60,11 +60,7 @@ typedef TgGeo<256, 256, 2, 4> TgGeoLarge;
 // covered by matrix work inside the wave (the compiler then waits with a partial lgkmcnt instead of lgkmcnt(0)).
 template <class PR, class GE, int GA_ = 0>
 TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[GE::FM][GE::FN]) {
-#ifdef TG_EXP_GA
-    constexpr int GA = GA_ ? GA_ : TG_EXP_GA;
-#else
-    constexpr int GA = GA_ ? GA_ : ((PR::NP == 2) ? 2 : 4);   // A fragments per block (register budget)
-#endif
+    constexpr int GA = GA_ ? GA_ : ((PR::NP == 2) ? 2 : 4);   // A fragments per block (register budget; 1/2/4 measure the same, run 17)
     constexpr int NB = GE::FM / GA;                           // blocks per k-chunk group
     constexpr int NG = PR::KQ * NB;                           // pipeline length
     const int r = lane & 15, g = lane >> 4;
@@ -96,13 +92,11 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
             load_a((i + 1) & 1, qn, bn);
         }
         TG_SCHED_FENCE();                                     // next block's LDS reads stay ahead of this block's MFMAs
-        TG_SETPRIO(1);
 #pragma unroll
         for (int fi = 0; fi < GA; ++fi)
 #pragma unroll
             for (int fj = 0; fj < GE::FN; ++fj)
                 acc[blk * GA + fi][fj] = PR::mma(a[i & 1][fi], b[q & 1][fj], acc[blk * GA + fi][fj]);
-        TG_SETPRIO(0);
         TG_SCHED_FENCE();
     }
 }
@@ -600,7 +594,6 @@ enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
 
 template <class PR, class GE, bool FULL>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
-    constexpr int PHASE = 1;
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
@@ -659,7 +652,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     // ---------------- epilogue ----------------
     float* red = (float*)tg_lds;        // LDS reuse: every wave is past the last barrier of the main loop
     const int g = lane >> 4, r15 = lane & 15;
-    constexpr int NP = (PHASE == 1) ? (FULL ? (int)TGP1_N : 1) : 2;
+    constexpr int NP = FULL ? (int)TGP1_N : 1;
     constexpr int FM = GE::FM, FN = GE::FN;
     constexpr int EB = GE::FM;                                 // spot quads whose global loads are in flight together (1 workgroup per CU: the epilogue needs its own memory-level parallelism)
     const int vbase = v0 + wm * (GE::TM / GE::WM) + 4 * g;      // + fi * 16
@@ -674,7 +667,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
         const float fg = a.fgate ? a.fgate[cc] : 1.f;
         const float wc = a.dens_w ? a.dens_w[cc] : 1.f;
         const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
-        if constexpr (PHASE == 1) {
+        {
 #pragma unroll
             for (int q = 0; q < NP; ++q) pacc[fj][q] = 0.f;
 #pragma unroll
@@ -720,22 +713,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
             }
         }
         // reduce over the 4 lane groups holding the same cell (different spots)
-        if constexpr (PHASE == 1) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                float x = pacc[fj][q];
-                x += tg_shfl_xor(x, 16);
-                x += tg_shfl_xor(x, 32);
-                pacc[fj][q] = x;
-            }
-        } else {
-#pragma unroll
-            for (int msk = 16; msk <= 32; msk <<= 1) {
-                const float om = tg_shfl_xor(pacc[fj][0], msk), os = tg_shfl_xor(pacc[fj][1], msk);
-                const float nmx = tg_fmax(pacc[fj][0], om);
-                pacc[fj][1] = pacc[fj][1] * tg_exp(pacc[fj][0] - nmx) + os * tg_exp(om - nmx);
-                pacc[fj][0] = nmx;
-            }
+        for (int q = 0; q < NP; ++q) {
+            float x = pacc[fj][q];
+            x += tg_shfl_xor(x, 16);
+            x += tg_shfl_xor(x, 32);
+            pacc[fj][q] = x;
         }
     }
     // combine the WM waves along the spot axis through LDS, then one store per cell
@@ -751,23 +734,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     if (t < GE::TN) {
         const int c = c0 + t;
         if (c < a.C) {
-            if constexpr (PHASE == 1) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int w = 0; w < GE::WM; ++w) sum += red[(w * NP + q) * GE::TN + t];
-                    a.part[((size_t)vt * NP + q) * a.C + c] = sum;
-                }
-            } else {
-                float mx = TG_NEG_BIG;
-#pragma unroll
-                for (int w = 0; w < GE::WM; ++w) mx = tg_fmax(mx, red[(w * NP + 0) * GE::TN + t]);
+            for (int q = 0; q < NP; ++q) {
                 float sum = 0.f;
 #pragma unroll
-                for (int w = 0; w < GE::WM; ++w) sum += red[(w * NP + 1) * GE::TN + t] * tg_exp(red[(w * NP + 0) * GE::TN + t] - mx);
-                a.part[((size_t)vt * 2 + 0) * a.C + c] = mx;
-                a.part[((size_t)vt * 2 + 1) * a.C + c] = sum;
+                for (int w = 0; w < GE::WM; ++w) sum += red[(w * NP + q) * GE::TN + t];
+                a.part[((size_t)vt * NP + q) * a.C + c] = sum;
             }
         }
     }
@@ -1176,16 +1148,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
 
 // entropy / L1 / L2 scalars (mapping_optimizer.py:224-231) from the per-row sums -> history row
 struct TgHistRegArgs { const float* rowq; int C; float* hist; float lambda_r, lambda_l1, lambda_l2; int constrained; };
-
-// deterministic sum of a [n] vector into out[0] (single block)
-TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_vec_sum(const float* x, int n, float* out, float scale, int accumulate) {
-    TG_LDS_DECL;
-    float* red = (float*)tg_lds;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
-    s = tg_block_sum_1024(s, red);
-    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s;
-}
 
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs(TgHistRegArgs a) {
     TG_LDS_DECL;
