@@ -160,3 +160,27 @@ def test_pipelined_schedule_matches_sequential(precision):
     assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1][:, :5], outs[2][1][:, :5]), "pipelined runs must be bit-reproducible"
     np.testing.assert_allclose(outs[0][1][:, :5], outs[1][1][:, :5], atol=5e-6 if precision != "bf16" else 1e-4, rtol=1e-6)
     assert np.abs(outs[0][0] - outs[1][0]).max() < (1e-4 if precision != "bf16" else 5e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4), (5, 1, 7), (3, 2, 1), (1, 4, 6), (17, 130, 9), (18, 250, 9852), (70000, 8, 70)])
+def test_degenerate_and_extreme_shapes(shape):
+    """Single cell / gene / spot, a clusters-mode shape (18 x 250 x 9852) and a tall shape (grid limits)."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    C, K, V = shape
+    rng = np.random.default_rng(C * 100 + K * 10 + V)
+    S = rng.integers(1, 5, size=(C, K)).astype(np.float32)
+    G = rng.integers(1, 5, size=(V, K)).astype(np.float32)
+    d = (G.sum(1) / G.sum()).astype(np.float32)
+    M0 = rng.normal(size=(C, V)).astype(np.float32)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    for prec in ("fp32", "bf16x3"):
+        e = HipMapperEngine(S, G, M0, d=d, device=DEV, precision=prec, lambdas=lam)
+        hist = e.new_history(3)
+        e.step(3, 0.1, hist)
+        o = orc.OracleMapper(S, G, d=d, M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(3, 0.1)
+        np.testing.assert_allclose(hist[:, _capi.H_TOTAL].cpu().numpy(), np.array(ho["total_loss"]), atol=2e-5, err_msg=prec)
+        np.testing.assert_allclose(e.result().cpu().numpy(), Po, atol=5e-5, err_msg=prec)
+        np.testing.assert_allclose(e.project().cpu().numpy(), Po.T @ S.astype(np.float64), rtol=2e-4, atol=1e-5, err_msg=prec)

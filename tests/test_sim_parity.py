@@ -101,3 +101,26 @@ def test_emulated_cell_band_pipeline(sim, bands, tile):
     Po, ho = o.train(4, 0.1)
     np.testing.assert_allclose(outs[1][1][:, 0], np.array(ho["total_loss"]), atol=1e-5)
     assert np.abs(outs[1][0] - Po).max() < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4), (5, 1, 7), (3, 2, 1), (1, 4, 6), (17, 130, 9)])
+def test_emulated_degenerate_shapes(sim, shape):
+    """Tiny / degenerate problem sizes (single cell, single gene, single spot, K spilling into a second gene tile)."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V = shape
+    rng = np.random.default_rng(C * 100 + K * 10 + V)
+    S = rng.integers(1, 5, size=(C, K)).astype(np.float32)
+    G = rng.integers(1, 5, size=(V, K)).astype(np.float32)
+    d = (G.sum(1) / G.sum()).astype(np.float32)
+    M0 = rng.normal(size=(C, V)).astype(np.float32)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    e = HipMapperEngine(S, G, M0, d=d, device="cpu", precision="fp32", lambdas=lam)
+    hist = e.new_history(3)
+    e.step(3, 0.1, hist)
+    o = orc.OracleMapper(S, G, d=d, M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(3, 0.1)
+    from tangram_amd import _capi
+    np.testing.assert_allclose(hist[:, _capi.H_TOTAL].numpy(), np.array(ho["total_loss"]), atol=2e-5)
+    np.testing.assert_allclose(e.result().numpy(), Po, atol=2e-5)
+    np.testing.assert_allclose(e.project().numpy(), Po.T @ S.astype(np.float64), rtol=1e-4, atol=1e-5)
