@@ -9,7 +9,7 @@ export PYTHONUNBUFFERED=1
 (rocminfo | grep -E "Marketing|gfx" | head -4; nproc; lscpu | grep "Model name") > $O/env.log 2>&1
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
-echo "== bench default"; /usr/bin/time -v timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$?"; grep -E "Elapsed|Maximum resident" $O/bench_default.err
+echo "== bench default"; SECONDS=0; timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "rc=$? wall=${SECONDS}s"; tail -3 $O/bench_default.err
 echo "== 2-rank gloo smoke"; TG_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo "rc=$?"; tail -c 400 $O/bench_2rank_gloo.json
 echo "== rocprof of the same command"
 cd /tmp && export TMPDIR=/tmp

@@ -628,7 +628,8 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     e.dG = m->ws + L.o_dG;
     e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) : nullptr;
     e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
-    TG_LAUNCH((tg_dghat_emit<PR>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
+    if (e.extra) TG_LAUNCH((tg_dghat_emit<PR, true>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
+    else TG_LAUNCH((tg_dghat_emit<PR, false>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
     tg_prof_mark(m, "tg_dghat_emit");
     return TG_OK;
 }

@@ -539,8 +539,9 @@ struct TgEmitArgs {
     int V, Vr, Kp, K, n_aug;   // columns K+1 .. K+n_aug-1 carry the cell-type gradient
 };
 
-template <class PR>
+template <class PR, bool EXTRA>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
+    constexpr int NQ = PR::CH / 4;                       // float4 groups per operand chunk
     const int nch = a.Kp / PR::CH;
     const int vbeg = blockIdx.x * TG_RB;
     const size_t pitch = (size_t)(a.Kp / PR::BKE) * 128;
@@ -552,14 +553,19 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
         const float va = a.vcoef[v], vb = a.vcoef[a.Vr + v];
         float x[PR::CH];
 #pragma unroll
-        for (int e = 0; e < PR::CH; ++e) {
-            const size_t off = (size_t)v * a.Kp + k + e;
-            const float gh = a.Ghat[off], g = a.G[off];
-            float val = (a.coef[k + e] + va) * g + (a.coef[a.Kp + k + e] + vb) * gh;
-            const float ex = a.extra ? a.extra[off] : 0.f;
-            if (k + e < a.K) val += ex;
-            else val = (k + e > a.K && k + e < a.K + a.n_aug) ? ex : 0.f;
-            x[e] = val;
+        for (int q = 0; q < NQ; ++q) {
+            const size_t off = (size_t)v * a.Kp + k + 4 * q;
+            const f32x4 gh = *(const f32x4*)(a.Ghat + off), g = *(const f32x4*)(a.G + off);
+            const f32x4 ca = *(const f32x4*)(a.coef + k + 4 * q), cb = *(const f32x4*)(a.coef + a.Kp + k + 4 * q);
+            f32x4 ex = {0.f, 0.f, 0.f, 0.f};
+            if (EXTRA) ex = *(const f32x4*)(a.extra + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = k + 4 * q + e;
+                float val = (ca[e] + va) * g[e] + (cb[e] + vb) * gh[e] + ex[e];       // gene columns
+                if (kk >= a.K) val = (EXTRA && kk > a.K && kk < a.K + a.n_aug) ? ex[e] : 0.f;   // augmentation / padding columns
+                x[4 * q + e] = val;
+            }
         }
         tg_store_operand_chunk<PR>(a.dG + (size_t)v * pitch, k / PR::BKE, (k % PR::BKE) / PR::CH, x);
     }
