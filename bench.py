@@ -36,8 +36,8 @@ def kernel_model(name, C, K, V):
     if name == "tg_fwd_kernel":
         return 4.0 * C * V + small, gemm            # read M once, S once, write Ghat
     if name == "tg_bwd_kernel":
-        return 4.0 * C * V + small, gemm            # read M once, S and dGhat once (the stored X is implementation traffic)
-    if name == "tg_adam_update":
+        return 4.0 * C * V + small, gemm            # S and dGhat once, one C x V fp32 plane (X out; M in on the sharded path)
+    if name in ("tg_adam_rowpass", "tg_adam_update"):
         return 24.0 * C * V, 0.0                    # read+write M, Adam m, Adam v (the X read is implementation traffic)
     return None, None
 

@@ -24,7 +24,7 @@ for f in sorted(glob.glob(sys.argv[1]+"/*.json")):
     except Exception as e: print("parse fail",f); continue
     b=os.path.basename(f)[:-5]; key=b.rsplit("_r",1)[0]
     k={x["name"]:x["avg_ms"] for x in d["kernels"]}
-    rows[key].append((d["ms_per_step"],k.get("tg_fwd_kernel",0),k.get("tg_bwd_kernel",0),k.get("tg_adam_update",0),d["last_main_loss"]))
+    rows[key].append((d["ms_per_step"],k.get("tg_fwd_kernel",0),k.get("tg_bwd_kernel",0),(k.get("tg_adam_update",0)+k.get("tg_adam_rowpass",0)),d["last_main_loss"]))
 for key,v in rows.items():
     print("%-44s"%key," | ".join("step %.3f fwd %.3f bwd %.3f adam %.3f"%x[:4] for x in v), " loss %.6f"%v[0][4])
 PY

@@ -259,13 +259,16 @@ static void tg_prof_mark(tg_mapper* m, const char* name) {
     m->prof_names.push_back(name);
 }
 
+static constexpr int TG_ROWPASS_MAX_V = 16384;        // tg_adam_rowpass: 512 threads x 8 float4 per array
+
 template <class PR, class GE>
 static int tg_lds_attr() {
 #ifndef TG_SIM
     const int bytes = GE::LDS_BYTES;
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 #endif
     return TG_OK;
 }
@@ -634,9 +637,10 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     return TG_OK;
 }
 
-// backward GEMM (X, row-dot partials) over the cell tiles [ct0, ct1) on `stream`
+// backward GEMM (X, row-dot partials) over the cell tiles [ct0, ct1) on `stream`; `x_only`: no row dots (they are
+// taken by tg_adam_rowpass)
 template <class PR>
-static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1) {
+static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bool x_only = false) {
     const TgLayout& L = m->L;
     TgBwdArgs a;
     a.dG = m->ws + L.o_dG;
@@ -657,11 +661,13 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1) {
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
     const int grid = tg_tilemap_grid(a.map);
     if (L.T == 256) {
-        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
     } else {
-        if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
+        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
+        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
     }
 }
 
@@ -698,7 +704,22 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
 
 // streaming softmax-backward + Adam over the cells [c0, c1); `finalize`: write the next softmax statistics directly
 // (single GPU, no filter)
-static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t stream = nullptr, int c0 = 0, int c1 = -1) {
+template <bool FULL, bool X16>
+static void tg_launch_rowpass(const TgUpdateArgs& u, int rows, int V, tg_stream_t stream) {
+#define TG_RP(NQ, NT) TG_LAUNCH((tg_adam_rowpass<FULL, X16, NQ, NT>), rows, 1, NT, 256, stream, u)
+    if (V <= 4096) {                                  // 256 threads, up to 4 quads each
+        const int nq = (V + 1023) / 1024;
+        if (nq <= 1) TG_RP(1, 256); else if (nq <= 2) TG_RP(2, 256); else TG_RP(4, 256);
+    } else {                                          // 512 threads, up to 8 quads each (V <= TG_ROWPASS_MAX_V)
+        const int nq = (V + 2047) / 2048;
+        if (nq <= 3) TG_RP(3, 512); else if (nq <= 4) TG_RP(4, 512); else if (nq <= 5) TG_RP(5, 512);
+        else if (nq <= 6) TG_RP(6, 512); else TG_RP(8, 512);
+    }
+#undef TG_RP
+}
+
+static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t stream = nullptr, int c0 = 0, int c1 = -1,
+                            bool rowpass = false) {
     const TgLayout& L = m->L;
     const bool whole = c1 < 0;
     if (whole) { stream = m->stream; c0 = 0; c1 = L.C; }
@@ -709,7 +730,7 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     u.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     u.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
     u.vcoef = m->fp(L.o_vcoef); u.r = m->fp(L.o_rowq);
-    u.pair_out = m->fp(L.o_rowpair);
+    u.pair_out = m->fp(L.o_rowpair); u.rowq_out = m->fp(L.o_rowq);
     u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_scale = m->fp(L.o_rscale);
     u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0; u.c_begin = c0;
     u.lambda_r = m->cfg.lambda_r; u.lambda_l1 = m->cfg.lambda_l1; u.lambda_l2 = m->cfg.lambda_l2;
@@ -718,6 +739,12 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
     u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
     const bool x16 = (m->cfg.precision == TG_PREC_BF16);     // PrecBF16::X16
+    if (rowpass) {
+        if (L.full) { if (x16) tg_launch_rowpass<true, true>(u, c1 - c0, L.V, stream); else tg_launch_rowpass<true, false>(u, c1 - c0, L.V, stream); }
+        else { if (x16) tg_launch_rowpass<false, true>(u, c1 - c0, L.V, stream); else tg_launch_rowpass<false, false>(u, c1 - c0, L.V, stream); }
+        if (whole) tg_prof_mark(m, "tg_adam_rowpass");
+        return TG_OK;
+    }
     if (L.full) { if (x16) TG_LAUNCH((tg_adam_update<true, true>), c1 - c0, 1, 256, 64, stream, u); else TG_LAUNCH((tg_adam_update<true, false>), c1 - c0, 1, 256, 64, stream, u); }
     else { if (x16) TG_LAUNCH((tg_adam_update<false, true>), c1 - c0, 1, 256, 64, stream, u); else TG_LAUNCH((tg_adam_update<false, false>), c1 - c0, 1, 256, 64, stream, u); }
     if (whole) tg_prof_mark(m, "tg_adam_update");
@@ -730,9 +757,21 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_forward<PR>(m))) return rc;
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
-    if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
     const bool constrained = (m->cfg.mode == TG_MODE_CONSTRAINED);
-    if ((rc = tg_launch_update(m, lr, !constrained))) return rc;
+    if (m->L.V <= TG_ROWPASS_MAX_V) {
+        // a row of M and X fits the registers of one workgroup: the backward GEMM only stores X, the row dots are fused
+        // into the update (tg_adam_rowpass), which also leaves the regulariser row sums for tg_hist_regs / the filter
+        tg_launch_bwd<PR>(m, m->stream, 0, m->L.nct, true);
+        tg_prof_mark(m, "tg_bwd_kernel");
+        if ((rc = tg_launch_update(m, lr, !constrained, nullptr, 0, -1, true))) return rc;
+        if (m->L.full) {
+            tg_launch_hist_regs(m, m->stream, hist_row);
+            tg_prof_mark(m, "tg_hist_regs");
+        }
+    } else {
+        if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
+        if ((rc = tg_launch_update(m, lr, !constrained))) return rc;
+    }
     if (constrained) {      // Adam on F, then fold the NEW filter into the forward row scale
         if ((rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
         if ((rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false))) return rc;

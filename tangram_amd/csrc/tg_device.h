@@ -6,6 +6,7 @@
 //             (the authoring container has no GPU).  Nothing in the product loads a TG_SIM build.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

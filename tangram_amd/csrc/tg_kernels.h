@@ -598,7 +598,7 @@ struct TgBwdArgs {
 };
 enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
 
-template <class PR, class GE, bool FULL>
+template <class PR, class GE, bool FULL, bool ROWDOT>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
@@ -656,6 +656,28 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     }
 
     // ---------------- epilogue ----------------
+    if constexpr (!ROWDOT) {
+        // single-GPU schedule: only X = S dGhat^T leaves the kernel; the row dots are taken by tg_adam_rowpass, which
+        // holds a whole row of M and X in registers (saves the M read, the exponentials and the partial-sum traffic here)
+        const int g = lane >> 4, r15 = lane & 15;
+        const int vbase = v0 + wm * (GE::TM / GE::WM) + 4 * g;
+#pragma unroll
+        for (int fj = 0; fj < GE::FN; ++fj) {
+            const int c = c0 + wn * (GE::TN / GE::WN) + fj * 16 + r15;
+            if (c >= a.C) continue;
+#pragma unroll
+            for (int fi = 0; fi < GE::FM; ++fi) {
+                const int v = vbase + fi * 16;
+                if (v >= a.Vp) continue;
+                if constexpr (PR::X16)
+                    *(u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v) =
+                        u32x2{tg_pack_bf16(acc[fi][fj][0], acc[fi][fj][1]), tg_pack_bf16(acc[fi][fj][2], acc[fi][fj][3])};
+                else
+                    *(f32x4*)((float*)a.X + (size_t)c * a.Vp + v) = acc[fi][fj];
+            }
+        }
+        return;
+    } else {
     float* red = (float*)tg_lds;        // LDS reuse: every wave is past the last barrier of the main loop
     const int g = lane >> 4, r15 = lane & 15;
     constexpr int NP = FULL ? (int)TGP1_N : 1;
@@ -748,6 +770,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
                 a.part[((size_t)vt * NP + q) * a.C + c] = sum;
             }
         }
+    }
     }
 }
 
@@ -1048,6 +1071,7 @@ struct TgUpdateArgs {
     const float* vcoef;                               // a_v at [2*Vr + v]
     const float* r;                                   // [C] row dots
     float* pair_out;                                  // [2][C] (max, Z) of the new row (cross-GPU exchange)
+    float* rowq_out;                                  // [TGP1_N][C] row sums written by tg_adam_rowpass (FULL), else unused
     float* new_shift; float* new_invz; float* new_scale;   // finalised statistics (single GPU) or null
     int C, V, Vp, Vr, finalize;
     int c_begin;                                      // first cell of this launch (grid = number of cells)
@@ -1129,6 +1153,158 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
             a.new_shift[c] = mx;
             a.new_invz[c] = inz;
             a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;      // (the constrained filter is folded in by tg_merge_stats)
+        }
+    }
+}
+
+// K4': the same update for the single-GPU schedule, with the softmax-backward row dot taken in the SAME kernel:
+// one workgroup of NT threads per cell holds its whole row of M, X and both moments in registers (NQ float4 per thread
+// per array, V <= 4 * NT * NQ; every load of the row is in flight before the first use),
+//   pass 1: P, dP -> r_c (block reduction; plus the entropy / L1 / L2 / filter row sums when FULL),
+//   pass 2: dM = P (dP - r_c), Adam, stores, (max, sum exp) of the new row.
+// HBM traffic is that of tg_adam_update; tg_bwd_kernel no longer reads M nor writes row-dot partials.
+template <bool FULL, bool X16, int NQ, int NT>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(TgUpdateArgs a) {
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;          // [NW waves][TGP1_N] then [NW][2]
+    constexpr int NW = NT / 64;
+    constexpr int NP = FULL ? (int)TGP1_N : 1;
+    const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float sh = a.rshift[c], iz = a.rinvz[c];
+    const float fg = a.fgate ? a.fgate[c] : 1.f;
+    const float wc = a.dens_w ? a.dens_w[c] : 1.f;
+    const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
+    const size_t row = (size_t)c * a.Vp;
+    const float* avec = a.vcoef + 2 * (size_t)a.Vr;
+    f32x4 mq[NQ];
+    typename std::conditional<X16, u32x2, f32x4>::type xr[NQ];
+    auto xval = [&](int q) -> f32x4 {
+        if constexpr (X16) return f32x4{tg_bf16_lo_to_f32(xr[q][0]), tg_bf16_hi_to_f32(xr[q][0]), tg_bf16_lo_to_f32(xr[q][1]), tg_bf16_hi_to_f32(xr[q][1])};
+        else return xr[q];
+    };
+    // ---- pass 1: loads (all in flight together) and the row sums
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int v = 4 * (t + NT * q);
+        const int vl = v < a.V ? v : 0;
+        mq[q] = *(const f32x4*)(a.M + row + vl);
+        if constexpr (X16) xr[q] = *(const u32x2*)((const unsigned short*)a.X + row + vl);
+        else xr[q] = *(const f32x4*)((const float*)a.X + row + vl);
+    }
+    f32x4 m1q[NQ], m2q[NQ];                              // the moments travel while pass 1 computes
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int v = 4 * (t + NT * q);
+        const int vl = v < a.V ? v : 0;
+        m1q[q] = *(const f32x4*)(a.am + row + vl);
+        m2q[q] = *(const f32x4*)(a.av + row + vl);
+    }
+    float acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int v = 4 * (t + NT * q);
+        if (v >= a.V) continue;
+        const f32x4 aq = *(const f32x4*)(avec + v);
+        const f32x4 xq = xval(q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if ((v + e) >= a.V) continue;
+            const float mo = mq[q][e];
+            const float p = tg_exp(mo - sh) * iz;
+            float dp = fg * (xq[e] + aq[e] * wc);
+            if (FULL) {
+                if (a.lambda_r != 0.f) {
+                    const float lp = (mo - sh) + logiz;
+                    dp -= a.lambda_r * (lp + 1.f);
+                    acc[TGP1_ENT % NP] += p * lp;
+                }
+                acc[TGP1_Q % NP] += p * xq[e];
+                acc[TGP1_PA % NP] += p * aq[e];
+                acc[TGP1_L1 % NP] += fabsf(mo);
+                acc[TGP1_L2 % NP] += mo * mo;
+            }
+            acc[TGP1_R] += p * dp;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        float x = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x += tg_shfl_xor(x, m);
+        if (lane == 0) red[wave * NP + i] = x;
+    }
+    __syncthreads();
+    float rc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) rc += red[w * NP + TGP1_R];
+    if (FULL && t < NP) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) x += red[w * NP + t];
+        a.rowq_out[(size_t)t * a.C + c] = x;
+    }
+    __syncthreads();                                   // `red` is reused below
+    // ---- pass 2: Adam on the registers held since pass 1
+    float lmax = TG_NEG_BIG, lsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int v = 4 * (t + NT * q);
+        if (v >= a.V) continue;
+        f32x4 m1 = m1q[q], m2 = m2q[q];
+        const f32x4 aq = *(const f32x4*)(avec + v);
+        const f32x4 xq = xval(q);
+        f32x4 mo4 = mq[q];
+        float nm[4];
+        float qmax = TG_NEG_BIG;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = (v + e) < a.V;
+            const float mo = mo4[e];
+            const float p = tg_exp(mo - sh) * iz;
+            float dp = fg * (xq[e] + aq[e] * wc);
+            if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + logiz + 1.f);
+            float gm = p * (dp - rc);
+            if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
+            if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
+            const float e1 = m1[e] + (gm - m1[e]) * (1.f - a.beta1);
+            const float e2 = m2[e] * a.beta2 + (1.f - a.beta2) * gm * gm;
+            const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
+            const float mn = mo - a.step_size * (e1 / den);
+            if (ok) { mo4[e] = mn; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mn); }
+            nm[e] = ok ? mn : TG_NEG_BIG;
+        }
+        *(f32x4*)(a.M + row + v) = mo4;
+        *(f32x4*)(a.am + row + v) = m1;
+        *(f32x4*)(a.av + row + v) = m2;
+        const float nmx = tg_fmax(lmax, qmax);
+        float qs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qs += (nm[e] > TG_NEG_BIG) ? tg_exp(nm[e] - nmx) : 0.f;
+        lsum = lsum * tg_exp(lmax - nmx) + qs;
+        lmax = nmx;
+    }
+#pragma unroll
+    for (int msk = 1; msk <= 32; msk <<= 1) {
+        const float om = tg_shfl_xor(lmax, msk), os = tg_shfl_xor(lsum, msk);
+        const float nmx = tg_fmax(lmax, om);
+        lsum = lsum * tg_exp(lmax - nmx) + os * tg_exp(om - nmx);
+        lmax = nmx;
+    }
+    if (lane == 0) { red[wave * 2] = lmax; red[wave * 2 + 1] = lsum; }
+    __syncthreads();
+    if (t == 0) {
+        float mx = red[0];
+        for (int w = 1; w < NW; ++w) mx = tg_fmax(mx, red[w * 2]);
+        float z = 0.f;
+        for (int w = 0; w < NW; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
+        a.pair_out[c] = mx;
+        a.pair_out[a.C + c] = z;
+        if (a.finalize) {
+            a.new_shift[c] = mx;
+            a.new_invz[c] = 1.f / z;
+            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
         }
     }
 }
