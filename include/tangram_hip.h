@@ -152,6 +152,14 @@ int tg_mapper_result(tg_mapper* m, float* P_out_dev, float* F_out_dev);
 /* Replaces `adata_map.X.T @ S` (mapping_utils.py:402): Ghat_out_dev [V][K] = softmax(M)^T S (times f). */
 int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev);
 
+/* Replaces `adata_map.X.T @ adata_sc.X` of project_genes (utils.py:366-368) and of the train-score epilogue over any
+ * gene set (mapping_utils.py:402-410) without moving the C x V mapping to the host: out_dev[V][ld_out] (first n_genes
+ * columns) = softmax(M)^T S_dev, S_dev [C][ld_s] holding n_genes expression columns (all genes of adata_sc, in blocks
+ * of cfg.n_genes internally).  unfiltered != 0: in constrained mode use softmax(M) alone, as adata_map.X holds it
+ * (mapping_optimizer.py:637); 0: times the filter f, like the training forward.  GEMM precision = cfg.precision.  */
+int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t ld_s, int32_t n_genes, float* out_dev,
+                            int64_t ld_out, int32_t unfiltered);
+
 /* Replaces Mapper._val_loss_fn (mapping_optimizer.py:311-356), evaluated with the CURRENT logits:
  * out4_dev = { gene score + voxel score, gene score, sparsity-weighted gene score, normalised map entropy }.   */
 int tg_mapper_validate(tg_mapper* m, float* out4_dev);

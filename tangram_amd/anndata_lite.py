@@ -53,7 +53,7 @@ class AnnDataLite:
             if (idx < 0).any():
                 raise KeyError("unknown variable names")
         X = self.X[:, idx]
-        return AnnDataLite(X, obs=self.obs, var=self.var.iloc[idx], uns=self.uns, obsm=self.obsm, obsp=self.obsp)
+        return AnnDataLite(X, obs=self.obs, var=self.var.iloc[idx].copy(), uns=self.uns, obsm=self.obsm, obsp=self.obsp)
 
     def copy(self):
         return AnnDataLite(self.X.copy(), self.obs.copy(), self.var.copy(), dict(self.uns), dict(self.obsm), dict(self.obsp))

@@ -70,7 +70,7 @@ static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 #define TG_MAX_BANDS 16
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
-    size_t o_Sk, o_St, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
+    size_t o_Sk, o_St, o_StP, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
         o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X,
         o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[6][3],
         o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
@@ -146,6 +146,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
     L->o_Sk = take((size_t)L->Cr * L->Kp * L->ESZ);
     L->o_St = take((size_t)L->Kp * L->Cp * L->ESZ);
+    L->o_StP = take((size_t)L->Kp * L->Cp * L->ESZ);      // operand image of a block of genes handed to tg_mapper_project_genes
     L->o_dG = take((size_t)L->Vr * L->Kp * L->ESZ);
     L->o_Gp = take((size_t)L->Vr * L->Kp * 4);
     L->o_Ghat = take((size_t)L->Vr * L->Kp * 4);
@@ -278,7 +279,7 @@ template <class PR>
 static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     const TgLayout& L = m->L;
     TgPrepSArgs a;
-    a.S = in->S_dev; a.C = L.C; a.K = L.K;
+    a.S = in->S_dev; a.C = L.C; a.K = L.K; a.ldS = L.K;
     a.aug = m->cfg.has_d_source ? in->d_source_dev : nullptr;
     a.ct = L.has_ct ? in->ct_encode_dev : nullptr; a.T = L.T_ct;
     a.Sk = m->ws + L.o_Sk; a.Cr = L.Cr; a.Kp = L.Kp;
@@ -562,13 +563,14 @@ static void tg_band_range(const TgLayout& L, int b, int* ct0, int* ct1, int* c0,
 }
 
 template <class PR>
-static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int band = -1) {
+static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int band = -1,
+                             const unsigned char* St_alt = nullptr, const float* rlse2_alt = nullptr) {
     const TgLayout& L = m->L;
     if (band < 0) stream = m->stream;
     TgFwdArgs a;
     a.M = (const float*)(m->st + L.s_M);
-    a.rlse2 = m->fp(L.o_rscale);
-    a.St = m->ws + L.o_St;
+    a.rlse2 = rlse2_alt ? rlse2_alt : m->fp(L.o_rscale);
+    a.St = St_alt ? St_alt : m->ws + L.o_St;
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
     a.nkt = L.nkt; a.nvt = L.nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
@@ -928,6 +930,46 @@ extern "C" int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev) {
     if (rc) return rc;
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     TG_CK(tg_memcpy2d(Ghat_out_dev, (size_t)L.K * 4, m->ws + L.o_Ghat, (size_t)L.Kp * 4, (size_t)L.K * 4, L.V, m->stream));
+    return TG_OK;
+}
+
+template <class PR>
+static int tg_project_block(tg_mapper* m, const float* S_blk, long long ld_s, int kc, const float* rlse2_alt) {
+    const TgLayout& L = m->L;
+    TgPrepSArgs a;
+    a.S = S_blk; a.C = L.C; a.K = kc; a.ldS = ld_s; a.aug = nullptr; a.ct = nullptr; a.T = 0;
+    a.Sk = nullptr; a.Cr = L.Cr; a.Kp = L.Kp;
+    a.St = m->ws + L.o_StP; a.Cp = L.Cp;
+    const size_t n2 = (size_t)L.Kp * (L.Cp / PR::CH);
+    TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
+    return tg_launch_forward<PR>(m, nullptr, -1, m->ws + L.o_StP, rlse2_alt);
+}
+
+extern "C" int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t ld_s, int32_t n_genes, float* out_dev,
+                                       int64_t ld_out, int32_t unfiltered) {
+    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
+    if (!S_dev || !out_dev) return tg_fail(TG_ERR_INVALID, "S or out is NULL");
+    if (n_genes < 1 || ld_s < n_genes || ld_out < n_genes) return tg_fail(TG_ERR_INVALID, "n_genes < 1 or a row pitch smaller than n_genes");
+    const TgLayout& L = m->L;
+    const float* rlse2_alt = nullptr;
+    if (unfiltered && m->cfg.mode == TG_MODE_CONSTRAINED) {     // adata_map.X is softmax(M) without the filter (mapping_optimizer.py:637)
+        TG_LAUNCH(tg_plain_rscale, (L.C + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_rshift),
+                  (const float*)m->fp(L.o_rinvz), L.C, m->fp(L.o_rowent));
+        rlse2_alt = m->fp(L.o_rowent);
+    }
+    for (int k0 = 0; k0 < n_genes; k0 += L.K) {
+        const int kc = (n_genes - k0 < L.K) ? n_genes - k0 : L.K;
+        int rc;
+        switch (m->cfg.precision) {
+            case TG_PREC_F32: rc = tg_project_block<PrecF32>(m, S_dev + k0, ld_s, kc, rlse2_alt); break;
+            case TG_PREC_BF16: rc = tg_project_block<PrecBF16>(m, S_dev + k0, ld_s, kc, rlse2_alt); break;
+            default: rc = tg_project_block<PrecBF16x3>(m, S_dev + k0, ld_s, kc, rlse2_alt); break;
+        }
+        if (rc) return rc;
+        if ((rc = tg_launch_ghat_stats(m))) return rc;
+        TG_CK(tg_memcpy2d(out_dev + k0, (size_t)ld_out * 4, m->ws + L.o_Ghat, (size_t)L.Kp * 4, (size_t)kc * 4, L.V, m->stream));
+    }
+    TG_CK(tg_check_launch());
     return TG_OK;
 }
 

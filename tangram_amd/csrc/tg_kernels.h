@@ -1438,6 +1438,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
     }
 }
 
+// forward row scale WITHOUT the constrained-mode filter: (max + ln Z) * log2(e)
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_plain_rscale(const float* rshift, const float* rinvz, int C, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) out[c] = (rshift[c] - tg_log(rinvz[c])) * TG_LOG2E;
+}
+
 // one block per row: (max, sum exp) of a row of M (initialisation / fallback path)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_row_stats(const float* M, int C, int V, int Vp, float* part /*[1][2][C]*/) {
     TG_LDS_DECL;
@@ -1528,7 +1534,8 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_val_finalize(TgValArgs a) {
 // set-up kernels: operand images of S and the padded fp32 copy of G
 // ----------------------------------------------------------------------------------------------
 struct TgPrepSArgs {
-    const float* S; int C, K;           // caller's [C][K]
+    const float* S; int C, K;           // caller's [C][K] (row pitch ldS elements)
+    long long ldS;
     const float* aug;                   // [C] values of the augmentation column K (null => 1)
     const float* ct; int T;             // [C][T] cell-type encoding -> columns K+1 .. K+T (ct-islands term), or null
     unsigned char* Sk; int Cr, Kp;      // [Cr][Kp/BKE][128 B]   (contraction over genes)
@@ -1536,7 +1543,7 @@ struct TgPrepSArgs {
 };
 TG_DEV float tg_s_aug(const TgPrepSArgs& a, int c, int k) {
     if (c >= a.C) return 0.f;
-    if (k < a.K) return a.S[(size_t)c * a.K + k];
+    if (k < a.K) return a.S[(size_t)c * a.ldS + k];
     if (k == a.K) return a.aug ? a.aug[c] : 1.f;
     if (a.ct && k - a.K - 1 < a.T) return a.ct[(size_t)c * a.T + (k - a.K - 1)];
     return 0.f;

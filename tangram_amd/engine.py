@@ -178,6 +178,21 @@ class HipMapperEngine:
         _capi.check(self._lib.tg_mapper_project(self._h, Gh.data_ptr()))
         return Gh
 
+    def project_genes(self, S_all, unfiltered=True):
+        """softmax(M)^T S_all for ANY gene set ([C, K_all] float32 on this device or host array) -> [V, K_all] device
+        tensor; the C x V mapping never leaves the GPU (reference: `adata_map.X.T @ adata_sc.X`, utils.py:366-368)."""
+        S_all = torch.as_tensor(S_all)
+        if S_all.dim() != 2 or S_all.shape[0] != self.C:
+            raise ValueError("S_all must be [n_cells, n_genes] with the mapper's cells")
+        S_all = S_all.to(device=self.device, dtype=torch.float32)
+        if S_all.stride(1) != 1:
+            S_all = S_all.contiguous()
+        n = int(S_all.shape[1])
+        out = torch.empty((self.V, n), dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.tg_mapper_project_genes(self._h, S_all.data_ptr(), int(S_all.stride(0)), n, out.data_ptr(), n,
+                                                      1 if unfiltered else 0))
+        return out
+
     def validate(self):
         """(expression_sim, gv_sim, sparsity-weighted gv_sim, entropy) of the current mapping; one D2H copy."""
         out = torch.empty(4, dtype=torch.float32, device=self.device)

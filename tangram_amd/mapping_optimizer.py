@@ -167,9 +167,10 @@ class Mapper:
         return output, history
 
     # extras -----------------------------------------------------------------------------------------
-    def project_genes_device(self):
-        """softmax(M)^T S on the device (what mapping_utils.py:402 recomputes in NumPy)."""
-        return self._engine.project()
+    def project_genes_device(self, S_all=None):
+        """softmax(M)^T S on the device (what mapping_utils.py:402 and utils.py:368 compute in NumPy on the host);
+        `S_all` [n_cells, n_genes_any]: project another gene set (project_genes), default: the training genes."""
+        return self._engine.project() if S_all is None else self._engine.project_genes(S_all)
 
 
 _KEYS_CONSTRAINED = ["total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg", "count_reg", "lambda_f_reg"]  # :609-617
@@ -253,5 +254,7 @@ class MapperConstrained:
                 history[k].append(str(float(row[c]) if on else float("nan")))
         return P.detach().cpu().numpy(), F.detach().cpu().numpy(), history
 
-    def project_genes_device(self):
-        return self._engine.project()
+    def project_genes_device(self, S_all=None, unfiltered=True):
+        """Like Mapper.project_genes_device; `unfiltered`: softmax(M) alone, as `adata_map.X` holds it (:637), else times
+        the learned filter.  Without `S_all`: the (filtered) training-time projection."""
+        return self._engine.project() if S_all is None else self._engine.project_genes(S_all, unfiltered=unfiltered)

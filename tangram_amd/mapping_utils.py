@@ -212,7 +212,7 @@ def map_cells_to_space(
 
     # ---- per-gene training score, :401-410 (projection evaluated on the GPU; constrained: unfiltered like :402)
     if mode == "constrained":
-        G_predicted = (torch.as_tensor(mapping_matrix, device=device).t() @ torch.as_tensor(S, device=device)).cpu().numpy()
+        G_predicted = mapper.project_genes_device(S, unfiltered=True).cpu().numpy()
     else:
         G_predicted = mapper.project_genes_device().cpu().numpy()
     num = (G * G_predicted).sum(axis=0)
@@ -230,4 +230,8 @@ def map_cells_to_space(
     adata_map.uns["train_genes_df"]["sparsity_diff"] = (
         adata_sp[:, training_genes].var.sparsity - adata_sc[:, training_genes].var.sparsity)
     adata_map.uns["training_history"] = training_history                      # :426
+    try:        # keeps the trained mapping resident for tangram_amd.project_genes (not part of the AnnData contract)
+        object.__setattr__(adata_map, "_tangram_amd_mapper", mapper)
+    except Exception:
+        pass
     return adata_map

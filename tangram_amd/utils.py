@@ -1,0 +1,89 @@
+"""
+Device-side `project_genes` (reference: tangram/utils.py:338-375).  The reference multiplies the C x V mapping by the
+full single-cell matrix on the host (`adata_map.X.T @ adata_sc.X`, utils.py:368; 2*C*V*K_all flop, K_all ~ 26k genes
+in the tutorial); here the product runs in the forward GEMM kernel of the training loop (tg_mapper_project_genes),
+block of genes by block of genes, with the mapping resident in HBM.
+
+Same argument meaning, `ValueError` condition and result contract (`X` = spots x genes, `obs` = adata_map.var,
+`var` = adata_sc.var + `is_training`, `uns` = adata_sc.uns).  scanpy is not imported: the gene filter
+`sc.pp.filter_genes(min_cells=1)` (:357) and `var_names_make_unique` (:354) are restated on the duck-typed inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import mapping_utils as mu
+from .anndata_lite import AnnDataLite
+from .engine import HipMapperEngine
+
+
+def _make_unique(names):
+    """anndata's `var_names_make_unique` rule: later duplicates get -1, -2, ... appended."""
+    seen, out = {}, []
+    taken = set(names)
+    for n in names:
+        if n not in seen:
+            seen[n] = 0
+            out.append(n)
+            continue
+        while True:
+            seen[n] += 1
+            cand = "{}-{}".format(n, seen[n])
+            if cand not in taken:
+                break
+        taken.add(cand)
+        out.append(cand)
+    return out
+
+
+def _result(X, obs, var, uns):
+    try:
+        import anndata
+        return anndata.AnnData(X=X, obs=obs, var=var, uns=uns)
+    except Exception:
+        return AnnDataLite(X, obs=obs, var=var, uns=uns)
+
+
+def _projection_engine(adata_map, device, gemm_precision):
+    """A mapper whose softmax reproduces a GIVEN mapping matrix (used when the trained mapper is gone, e.g. an
+    adata_map loaded from disk): logits = log P, so softmax(logits) = P / sum_v P = P."""
+    P = torch.as_tensor(np.asarray(adata_map.X), dtype=torch.float32, device=device)
+    M0 = torch.log(P).clamp_(min=-1.0e30)
+    C, V = P.shape
+    S1 = torch.ones((C, 1), dtype=torch.float32, device=device)
+    G1 = torch.ones((V, 1), dtype=torch.float32, device=device)
+    return HipMapperEngine(S1, G1, M0, device=device, precision=gemm_precision, lambdas=dict(lambda_g1=1.0))
+
+
+def project_genes(adata_map, adata_sc, cluster_label=None, scale=True, *, mapper=None, device="cuda:0",
+                  gemm_precision="bf16x3"):
+    """Transfer gene expression from the single cell data onto space (reference utils.py:338-375).
+
+    Extra keywords: `mapper` -- the trained `Mapper`/`MapperConstrained` (default: the one `map_cells_to_space` left on
+    `adata_map`; if there is none, the mapping matrix `adata_map.X` is uploaded once); `device`, `gemm_precision` as
+    in `map_cells_to_space`."""
+    adata_sc.var.index = [g.lower() for g in adata_sc.var.index]                     # :351
+    adata_sc.var.index = _make_unique(list(adata_sc.var.index))                      # :354
+    X = adata_sc.X
+    n_cells = np.asarray((X != 0).sum(axis=0)).reshape(-1)                           # :357 filter_genes(min_cells=1)
+    keep = n_cells >= 1
+    if not keep.all():
+        adata_sc = adata_sc[:, list(adata_sc.var.index[keep])]
+    adata_sc.var["n_cells"] = n_cells[keep]
+    if cluster_label:                                                                # :359-360
+        adata_sc = mu.adata_to_cluster_expression(adata_sc, cluster_label, scale=scale)
+    if not adata_map.obs.index.equals(adata_sc.obs.index):                           # :362-363
+        raise ValueError("The two AnnDatas need to have same `obs` index.")
+    S_all = np.ascontiguousarray(mu._dense(adata_sc.X), dtype=np.float32)            # :364-365
+    if mapper is None:
+        mapper = getattr(adata_map, "_tangram_amd_mapper", None)
+    engine = mapper._engine if mapper is not None else _projection_engine(adata_map, torch.device(device), gemm_precision)
+    if engine.C != S_all.shape[0]:
+        raise ValueError("The two AnnDatas need to have same `obs` index.")
+    X_space = engine.project_genes(S_all, unfiltered=True).cpu().numpy()             # :366  (adata_map.X.T @ adata_sc.X)
+    adata_ge = _result(X_space, adata_map.var, adata_sc.var, adata_sc.uns)           # :367-369
+    training_genes = adata_map.uns["train_genes_df"].index.values                    # :370-371
+    adata_ge.var["is_training"] = adata_ge.var.index.isin(training_genes)
+    return adata_ge

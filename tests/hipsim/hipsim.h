@@ -2,7 +2,7 @@
 //
 // A tiny single-process emulator of the HIP execution model, just large enough to run the
 // kernels of tangram_amd/csrc on the CPU of the authoring container (which has no GPU):
-//   * one fiber (ucontext) per work-item, one workgroup at a time, wavefront = 64 lanes;
+//   * one fiber (own stack, hand-written context switch) per work-item, one workgroup at a time, wavefront = 64 lanes;
 //   * __syncthreads(), wave shuffles and the gfx950 MFMA builtins used by the kernels, with the
 //     lane->element layouts of /opt/skills/guides/cdna_hip_programming.md section 3;
 //   * "device memory" is host memory; a launch runs synchronously.
@@ -10,7 +10,12 @@
 // sequence can be checked against the oracle with `pytest -m "not gpu"`.  It says nothing about
 // speed, and data races are only visible as far as the deterministic fiber order exposes them.
 #pragma once
+#if defined(__x86_64__)
+#define HIPSIM_ASM_SWITCH 1          // hand-written context switch: swapcontext() costs two sigprocmask syscalls per switch
+#else
+#define HIPSIM_ASM_SWITCH 0
 #include <ucontext.h>
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -20,12 +25,50 @@
 #include <functional>
 #include <vector>
 
+#if HIPSIM_ASM_SWITCH
+struct hipsim_ctx { void* sp; };
+extern "C" __attribute__((visibility("hidden"))) void hipsim_switch(hipsim_ctx* from, hipsim_ctx* to);
+// saves the callee-saved registers of the SysV ABI on the current stack, swaps stack pointers, restores, returns
+asm(".text\n"
+    ".type hipsim_switch,@function\n"
+    "hipsim_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq (%rsi), %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size hipsim_switch, .-hipsim_switch\n");
+#endif
+
 namespace hipsim {
 
 struct uint3s { unsigned x, y, z; };
 
+#if HIPSIM_ASM_SWITCH
+typedef hipsim_ctx ctx_t;
+inline void ctx_switch(ctx_t* from, ctx_t* to) { hipsim_switch(from, to); }
+inline void ctx_make(ctx_t* c, char* stack, size_t size, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                  // fake return address of `entry` (it never returns)
+    *--sp = (void*)entry;             // popped by the `ret` of the first switch
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
+    c->sp = sp;
+}
+#else
+typedef ucontext_t ctx_t;
+inline void ctx_switch(ctx_t* from, ctx_t* to) { swapcontext(from, to); }
+inline void ctx_make(ctx_t* c, char* stack, size_t size, void (*entry)()) {
+    getcontext(c);
+    c->uc_stack.ss_sp = stack;
+    c->uc_stack.ss_size = size;
+    c->uc_link = nullptr;
+    makecontext(c, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    ctx_t ctx;
     char* stack = nullptr;
     uint3s tid{};
     int state = 0;            // 0 runnable, 1 waiting at block barrier, 2 done
@@ -44,7 +87,7 @@ struct Machine {
     uint3s gridDim{}, blockDim{}, blockIdx{};
     std::vector<Fiber> fibers;
     std::vector<WaveSlot> waves;
-    ucontext_t sched;
+    ctx_t sched;
     Fiber* cur = nullptr;
     int cur_index = 0;
     int barrier_arrived = 0;
@@ -55,13 +98,14 @@ struct Machine {
 
 inline Machine& M() { static Machine m; return m; }
 
-inline void yield_to_sched() { Machine& m = M(); swapcontext(&m.cur->ctx, &m.sched); }
+inline void yield_to_sched() { Machine& m = M(); ctx_switch(&m.cur->ctx, &m.sched); }
 
 inline void fiber_entry() {
     Machine& m = M();
     m.body();
     m.cur->state = 2;
-    swapcontext(&m.cur->ctx, &m.sched);
+    ctx_switch(&m.cur->ctx, &m.sched);
+    abort();                           // a finished fiber is never resumed
 }
 
 constexpr size_t kStack = 256 * 1024;
@@ -85,11 +129,7 @@ void run_block(F&& f) {
         fb.tid.x = i % m.blockDim.x;
         fb.tid.y = (i / m.blockDim.x) % m.blockDim.y;
         fb.tid.z = i / (m.blockDim.x * m.blockDim.y);
-        getcontext(&fb.ctx);
-        fb.ctx.uc_stack.ss_sp = fb.stack;
-        fb.ctx.uc_stack.ss_size = kStack;
-        fb.ctx.uc_link = &m.sched;
-        makecontext(&fb.ctx, (void (*)())fiber_entry, 0);
+        ctx_make(&fb.ctx, fb.stack, kStack, fiber_entry);
     }
     int done = 0;
     while (done < n) {
@@ -107,7 +147,7 @@ void run_block(F&& f) {
                     any = true;
                     m.cur = &fb;
                     m.cur_index = i;
-                    swapcontext(&m.sched, &fb.ctx);
+                    ctx_switch(&m.sched, &fb.ctx);
                     if (fb.state == 2) ++done;
                     progressed = true;
                 }

@@ -184,3 +184,51 @@ def test_degenerate_and_extreme_shapes(shape):
         np.testing.assert_allclose(hist[:, _capi.H_TOTAL].cpu().numpy(), np.array(ho["total_loss"]), atol=2e-5, err_msg=prec)
         np.testing.assert_allclose(e.result().cpu().numpy(), Po, atol=5e-5, err_msg=prec)
         np.testing.assert_allclose(e.project().cpu().numpy(), Po.T @ S.astype(np.float64), rtol=2e-4, atol=1e-5, err_msg=prec)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_project_genes_all_genes(precision, tol):
+    """tg_mapper_project_genes (reference utils.py:366-368, `adata_map.X.T @ adata_sc.X`): several gene blocks with a
+    ragged tail and a padded row pitch, against the float64 product of the SAME mapping; stated tolerance = max abs
+    error relative to the largest entry (fp32 GEMM round-off / split-bf16 / plain bf16 operands)."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.synthetic import make_workload, init_logits
+    C, K, V, K_all = 3000, 200, 1100, 730
+    w = make_workload(C, K, V, DEV, seed=3)
+    e = HipMapperEngine(w["S"], w["G"], init_logits(C, V, DEV, seed=1), d=w["d"], device=DEV, precision=precision,
+                        lambdas=dict(lambda_d=1.0))
+    e.step(5, 0.1, e.new_history(5))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    wide = (torch.rand((C, K_all + 6), generator=g) * (torch.rand((C, K_all + 6), generator=g) < 0.3)).to(DEV) * 7.0
+    S_all = wide[:, 3:3 + K_all]
+    out = e.project_genes(S_all)
+    want = e.result().double().t() @ S_all.double()
+    assert out.shape == (V, K_all)
+    assert float((out.double() - want).abs().max()) <= tol * float(want.abs().max())
+    # training genes through the same entry point == the training-time projection kernel output
+    np.testing.assert_allclose(e.project_genes(w["S"]).cpu().numpy(), e.project().cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_project_genes_full_size_linearity_cfg2():
+    """BASELINE.json shape: 2 500 genes (2.5 blocks) projected from the resident mapping.  Size-independent checks:
+    linearity in S (a gene scaled by 3 and a sum of two genes), column sums (sum_v Ghat[v,k] = sum_c S[c,k] because
+    rows of P sum to 1), and block-boundary consistency (a gene's projection does not depend on its block)."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.synthetic import make_workload, init_logits
+    C, K, V = 30000, 1000, 10000
+    w = make_workload(C, K, V, DEV, seed=0)
+    e = HipMapperEngine(w["S"], w["G"], init_logits(C, V, DEV, seed=42), d=w["d"], device=DEV, precision="bf16x3",
+                        lambdas=dict(lambda_d=1.0))
+    e.step(3, 0.1, e.new_history(3))
+    g = torch.Generator(device="cpu").manual_seed(1)
+    S_all = (torch.rand((C, 2500), generator=g) * (torch.rand((C, 2500), generator=g) < 0.3)).to(DEV) * 5.0
+    S_all[:, 2400] = 3.0 * S_all[:, 10]
+    S_all[:, 2401] = S_all[:, 20] + S_all[:, 1500]
+    S_all[:, 999] = S_all[:, 1000]                       # same gene on both sides of a block boundary
+    out = e.project_genes(S_all)
+    scale = float(out.abs().max())
+    assert float((out[:, 2400] - 3.0 * out[:, 10]).abs().max()) <= 2e-5 * scale
+    assert float((out[:, 2401] - (out[:, 20] + out[:, 1500])).abs().max()) <= 2e-5 * scale
+    assert float((out[:, 999] - out[:, 1000]).abs().max()) <= 1e-6 * scale
+    cs = out.double().sum(dim=0); want = S_all.double().sum(dim=0)
+    assert float(((cs - want).abs() / want.clamp(min=1.0)).max()) <= 2e-5

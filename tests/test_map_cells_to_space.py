@@ -137,3 +137,36 @@ def test_spatial_extension_terms_with_csr_graph(sim):
     hist = ad_map.uns["training_history"]
     np.testing.assert_allclose([float(x) for x in hist["total_loss"]], ho["total_loss"], atol=1e-5)
     np.testing.assert_allclose(ad_map.X, Po, atol=1e-5)
+
+
+def test_project_genes_on_device(sim):
+    """tangram_amd.project_genes (reference utils.py:338-375): all genes of adata_sc projected with the mapping resident
+    on the device; result contract + values against adata_map.X.T @ adata_sc.X."""
+    import tangram_amd as tg
+    ad_sc, ad_sp = _adatas(extra_genes=7)
+    ad_sc.var.index = [g.upper() for g in ad_sc.var.index]                 # the reference lower-cases (:351)
+    ad_sc.X = ad_sc.X.copy(); ad_sc.X[:, -1] = 0                           # an all-zero gene is dropped (:357)
+    ad_sc_train = AnnDataLite(ad_sc.X, obs=ad_sc.obs, var=pd.DataFrame(index=[g.lower() for g in ad_sc.var.index]), uns=ad_sc.uns)
+    ad_map = tg.map_cells_to_space(ad_sc_train, ad_sp, mode="cells", device="cpu", num_epochs=3, random_state=42,
+                                   verbose=False, gemm_precision="fp32")
+    ad_ge = tg.project_genes(ad_map, ad_sc, device="cpu", gemm_precision="fp32")
+    keep = [g.lower() for g in ad_sc.var.index]
+    assert ad_ge.X.shape == (25, 18) and list(ad_ge.var.index) == keep[:18]
+    assert list(ad_ge.obs.index) == list(ad_sp.obs.index)
+    assert ad_ge.var["is_training"].sum() == 12 and "n_cells" in ad_ge.var.columns
+    want = ad_map.X.astype(np.float64).T @ ad_sc_train.X[:, :18].astype(np.float64)
+    np.testing.assert_allclose(ad_ge.X, want, rtol=1e-5, atol=1e-6)
+    # without the live mapper (an adata_map restored from disk): the mapping matrix is uploaded once
+    object.__delattr__(ad_map, "_tangram_amd_mapper")
+    ad_ge2 = tg.project_genes(ad_map, ad_sc, device="cpu", gemm_precision="fp32")
+    np.testing.assert_allclose(ad_ge2.X, want, rtol=2e-5, atol=2e-6)
+    # clusters: the single-cell matrix is aggregated the same way as for the mapping (:359-360)
+    ad_map_c = tg.map_cells_to_space(ad_sc_train, ad_sp, mode="clusters", cluster_label="subclass_label", device="cpu",
+                                     num_epochs=3, random_state=42, verbose=False, gemm_precision="fp32")
+    ad_ge_c = tg.project_genes(ad_map_c, ad_sc, cluster_label="subclass_label", device="cpu", gemm_precision="fp32")
+    agg = tg.adata_to_cluster_expression(ad_sc_train, "subclass_label", scale=True)
+    np.testing.assert_allclose(ad_ge_c.X, ad_map_c.X.astype(np.float64).T @ agg.X[:, :18], rtol=1e-5, atol=1e-5)
+    # mismatching cells raise like the reference (:362-363)
+    bad = AnnDataLite(ad_sc.X[:-1], obs=ad_sc.obs.iloc[:-1], var=ad_sc.var.copy(), uns=ad_sc.uns)
+    with pytest.raises(ValueError, match="same `obs` index"):
+        tg.project_genes(ad_map, bad, device="cpu")

@@ -58,7 +58,7 @@ def test_emulated_large_tile_geometry(sim, precision):
     """Force the 256 x 256 / 512-thread geometry on a small ragged problem and compare one step with the oracle."""
     from tangram_amd.engine import HipMapperEngine
     from oracle import tangram_oracle as orc
-    C, K, V = 300, 40, 270            # 2 x 2 tiles of 256, ragged
+    C, K, V = 300, 24, 270            # 2 x 2 tiles of 256, ragged
     data = orc.make_synthetic(C, K, V, seed=9)
     M0 = orc.reference_init_M(C, V, 4)
     lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_r=1e-3)
@@ -82,23 +82,23 @@ def test_emulated_cell_band_pipeline(sim, bands, tile):
     """The 3-stream cell-band schedule (backward | Adam | next forward) must give the sequential schedule's results."""
     from tangram_amd.engine import HipMapperEngine
     from oracle import tangram_oracle as orc
-    C, K, V = 420, 24, 150
+    C, K, V = 420, 16, 150
     data = orc.make_synthetic(C, K, V, seed=13)
     M0 = orc.reference_init_M(C, V, 6)
     lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.4, lambda_r=1e-3)
     outs = []
     for pb in (1, bands):
-        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam,
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam,
                             tile_size=tile, pipeline_bands=pb)
-        hist = e.new_history(4)
-        e.step(3, 0.1, hist, 0)          # three steps in one call: steps 2 and 3 use the pre-launched forward
-        e.step(1, 0.1, hist, 3)
+        hist = e.new_history(3)
+        e.step(2, 0.1, hist, 0)          # two steps in one call: step 2 uses the pre-launched forward
+        e.step(1, 0.1, hist, 2)
         outs.append((e.result().numpy(), hist.numpy()))
     np.testing.assert_allclose(outs[0][1][:, :5], outs[1][1][:, :5], atol=2e-6, rtol=1e-6)
     # (the forward partial sums are cut at band boundaries instead of equal step ranges: fp32 summation order differs)
     np.testing.assert_allclose(outs[0][0], outs[1][0], atol=2e-5)
     o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
-    Po, ho = o.train(4, 0.1)
+    Po, ho = o.train(3, 0.1)
     np.testing.assert_allclose(outs[1][1][:, 0], np.array(ho["total_loss"]), atol=1e-5)
     assert np.abs(outs[1][0] - Po).max() < 2e-5
 
@@ -124,3 +124,53 @@ def test_emulated_degenerate_shapes(sim, shape):
     np.testing.assert_allclose(hist[:, _capi.H_TOTAL].numpy(), np.array(ho["total_loss"]), atol=2e-5)
     np.testing.assert_allclose(e.result().numpy(), Po, atol=2e-5)
     np.testing.assert_allclose(e.project().numpy(), Po.T @ S.astype(np.float64), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("precision,rtol", [("fp32", 2e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_emulated_project_genes_all_genes(sim, precision, rtol):
+    """tg_mapper_project_genes: softmax(M)^T S_all over a gene set wider than the training genes (several blocks of
+    cfg.n_genes, ragged last block, padded row pitch) against P^T S_all in float64 (reference utils.py:366-368)."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    import torch
+    C, K, V, K_all = 70, 9, 33, 31
+    data = orc.make_synthetic(C, K, V, seed=21)
+    rng = np.random.default_rng(5)
+    M0 = rng.normal(size=(C, V)).astype(np.float32)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision=precision,
+                        lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+    e.step(2, 0.1, e.new_history(2))
+    P = e.result().numpy().astype(np.float64)
+    wide = torch.as_tensor(rng.gamma(1.0, 2.0, size=(C, K_all + 5)).astype(np.float32))
+    S_all = wide[:, 2:2 + K_all]                                  # a view: row pitch 36 != 31
+    out = e.project_genes(S_all).numpy()
+    want = P.T @ S_all.numpy().astype(np.float64)
+    assert out.shape == (V, K_all)
+    assert np.abs(out - want).max() <= rtol * np.abs(want).max()
+    # the training state is untouched: the next step equals an uninterrupted run
+    e2 = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision=precision,
+                         lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+    h2 = e2.new_history(3); e2.step(3, 0.1, h2)
+    h1 = e.new_history(1); e.step(1, 0.1, h1)
+    np.testing.assert_array_equal(h1[0].numpy(), h2[2].numpy())
+    with pytest.raises(ValueError):
+        e.project_genes(np.zeros((C + 1, 4), np.float32))
+
+
+def test_emulated_project_genes_constrained_filter(sim):
+    """unfiltered=True: softmax(M)^T S (what adata_map.X.T @ S gives, mapping_optimizer.py:637); False: with the filter."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V = 40, 7, 19
+    data = orc.make_synthetic(C, K, V, seed=22)
+    rng = np.random.default_rng(6)
+    M0 = rng.normal(size=(C, V)).astype(np.float32)
+    F0 = rng.normal(size=(C,)).astype(np.float32)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], F0=F0, mode="constrained", device="cpu", precision="fp32",
+                        lambdas=dict(lambda_g1=1.0, lambda_d=1.0, lambda_count=1.0, lambda_f_reg=1.0), target_count=10)
+    e.step(2, 0.1, e.new_history(2))
+    P, F = e.result(with_filter=True)
+    P = P.numpy().astype(np.float64); F = F.numpy().astype(np.float64)
+    S_all = rng.gamma(1.0, 2.0, size=(C, 16)).astype(np.float32)
+    np.testing.assert_allclose(e.project_genes(S_all, unfiltered=True).numpy(), P.T @ S_all, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(e.project_genes(S_all, unfiltered=False).numpy(), P.T @ (S_all * F[:, None]), rtol=1e-5, atol=1e-6)
