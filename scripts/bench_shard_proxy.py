@@ -1,0 +1,48 @@
+"""Per-rank cost of the spot-sharded multi-GPU step on ONE GPU: rank 0 of an 8-way split of cfg2 (30k x 1k x 1250 of
+10 000 spots) driven through the real ShardedMapperEngine (phases + torch.distributed collectives on a 1-rank RCCL
+group), so the host-side enqueue cost and the kernel time of a shard are both visible."""
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tangram_amd.sharded import ShardedMapperEngine  # noqa: E402
+from tangram_amd.synthetic import make_workload, init_logits  # noqa: E402
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {}
+    for (C, K, V, parts, prec) in ((30000, 1000, 10000, 8, "bf16x3"), (30000, 1000, 10000, 4, "bf16x3"),
+                                   (30000, 1000, 10000, 2, "bf16x3"), (30000, 1000, 10000, 8, "bf16")):
+        Vl = V // parts
+        w = make_workload(C, K, V, dev, seed=0)
+        M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous()
+        e = ShardedMapperEngine(w["S"], w["G"][:Vl].contiguous(), M0, w["d"][:Vl].contiguous(), n_spots_total=V,
+                                device=dev, precision=prec, lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+        n = 100
+        hist = e.eng.new_history(n)
+        e.run(10, 0.1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.run(n, 0.1, hist)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        out[f"{C}x{K}x{Vl}_of_{parts}_{prec}"] = dict(ms_per_step=1e3 * t_all / n, host_enqueue_ms_per_step=1e3 * t_enq / n,
+                                                      main_loss=float(hist[-1, 1]))
+        del e, w, M0
+    print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,14 +79,18 @@ struct TgLayout {
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
-static int tg_choose_splits(int tiles, int nsteps, int slots) {
+// Number of cell-range splits of the forward GEMM: minimise a small cost model (microseconds, measured on MI355X at cfg2:
+// profiles/r01) of  rounds of workgroups x (steps per workgroup x time per step + fixed cost per workgroup)
+//                 + the write and re-read of the `s` partial copies of Ghat (tg_ghat_reduce streams them at ~1.5 TB/s).
+static int tg_choose_splits(int tiles, int nsteps, int slots, int precision, int tile_edge, size_t part_bytes) {
+    double t_step = precision == TG_PREC_F32 ? 7.7 : 2.4;       // 256^2 tile, one contraction step (bf16: 64 elements)
+    if (tile_edge != 256) t_step *= 0.5;                        // a quarter of the work on half a CU
     int best = 1;
-    double best_eff = 0.0;
-    for (int s = 1; s <= 32 && s <= nsteps / 8; ++s) {          // keep >= 8 contraction steps per workgroup
-        const long w = (long)tiles * s;
-        const long waves = (w + slots - 1) / slots;
-        const double eff = (double)w / (double)(waves * slots);
-        if (eff > best_eff + 0.03) { best_eff = eff; best = s; }
+    double best_cost = 1e30;
+    for (int s = 1; s <= 32 && (s == 1 || s <= nsteps / 8); ++s) {   // keep >= 8 contraction steps per workgroup
+        const long rounds = ((long)tiles * s + slots - 1) / slots;
+        const double cost = (double)rounds * ((double)((nsteps + s - 1) / s) * t_step + 8.0) + (double)s * (double)part_bytes * 2.0 / 1.5e6;
+        if (cost < best_cost * 0.995) { best_cost = cost; best = s; }
     }
     return best;
 }
@@ -130,7 +134,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
     const int slots = 256 * (L->T == 256 ? 1 : 2);
-    L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots);
+    L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots, cfg->precision, L->T, (size_t)L->Vr * L->Kp * 4);
     if (L->nsplit > nsteps) L->nsplit = nsteps;
     // cell-band software pipeline (backward GEMM | streaming Adam | next forward GEMM on three streams): single-GPU Mapper only.
     // Opt-in (pipeline_bands >= 2): measured SLOWER than the sequential schedule on MI355X (profiles/r01/run14): the 256^2 GEMM
