@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counter passes (one rocprofv3 run per counter group, --pmc only: no trace domains) for bench.py.
-# usage: gpu_pmc.sh tag precision
-TAG=${1:-pmc}; P=${2:-bf16}
+# usage: gpu_pmc.sh tag precision [traffic]      ("traffic": only the groups profiles/pmc_traffic.json is built from)
+TAG=${1:-pmc}; P=${2:-bf16}; MODE=${3:-all}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 rm -rf $R/gpurun_out/*; mkdir -p $O
@@ -11,6 +11,7 @@ grep -oE "^\s*(Name|name)\s*:\s*\S+" $O/counters_list.txt | awk '{print $NF}' | 
 i=0
 while read -r GROUP; do
   i=$((i+1))
+  if [ "$MODE" = traffic ]; then case "$GROUP" in SQ_VALU_MFMA*|TCC_HIT*|FETCH_SIZE|WRITE_SIZE|GRBM*) ;; *) continue;; esac; fi
   timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d $O/g$i -o p -- python $R/bench.py --steps 3 --warmup 1 --precision $P --no-cpu-baseline --no-alt > $O/g$i.log 2>&1
   echo "group $i [$GROUP] rc=$?"
 done <<'GROUPS'
