@@ -58,11 +58,14 @@ typedef TgGeo<256, 256, 2, 4> TgGeoLarge;
 // One contraction step of the workgroup tile: software-pipelined over (k-chunk group q) x (blocks of GA A-fragments):
 // the ds_read_b128 of the NEXT block are issued before the MFMAs of the current one, so that the LDS latency is
 // covered by matrix work inside the wave (the compiler then waits with a partial lgkmcnt instead of lgkmcnt(0)).
-template <class PR, class GE, int GA_ = 0>
-TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[GE::FM][GE::FN]) {
+// `hook(i)` runs once per group, between the LDS reads of group i+1 and the MFMAs of group i: the kernels issue their
+// global loads / LDS-DMA for the next step there, a few per group, instead of one burst of 8-16 vector-memory
+// instructions per wave right after the barrier (measured: backward -1 % bf16x3 / -4 % bf16, forward -2 % bf16x3).
+template <class PR, class GE, int GA_ = 0, class Hook>
+TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[GE::FM][GE::FN], Hook&& hook) {
     constexpr int GA = GA_ ? GA_ : ((PR::NP == 2) ? 2 : 4);   // A fragments per block (register budget; 1/2/4 measure the same, run 17)
     constexpr int NB = GE::FM / GA;                           // blocks per k-chunk group
-    constexpr int NG = PR::KQ * NB;                           // pipeline length
+    constexpr int NG = PR::KQ * NB;                           // pipeline length (groups per step)
     const int r = lane & 15, g = lane >> 4;
     const u32x4* sa = st + (wm * (GE::TM / GE::WM) + r) * 8;  // this lane's first A row
     const u32x4* sb = st + GE::A_CHUNKS + (wn * (GE::TN / GE::WN) + r) * 8;
@@ -91,6 +94,7 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
             if (qn != q) load_b(qn & 1, qn);
             load_a((i + 1) & 1, qn, bn);
         }
+        hook(i);
         TG_SCHED_FENCE();                                     // next block's LDS reads stay ahead of this block's MFMAs
 #pragma unroll
         for (int fi = 0; fi < GA; ++fi)
@@ -100,6 +104,12 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
         TG_SCHED_FENCE();
     }
 }
+
+template <class PR, class GE, int GA_ = 0>
+struct TgMmaShape {
+    static constexpr int GA = GA_ ? GA_ : ((PR::NP == 2) ? 2 : 4);
+    static constexpr int NG = PR::KQ * (GE::FM / GA);         // groups per step = calls of the hook
+};
 
 // ROWS x 128-byte slab (one contraction step) of an operand stored as [row][step][128 B]
 template <int ROWS, int NT>
@@ -125,10 +135,13 @@ struct TgKTile {
 // The same slab copied by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.  The LDS image of one
 // wave instruction is lane-linear (64 x 16 B = 8 tile rows), so the XOR swizzle is applied to the per-lane SOURCE
 // address (logical chunk = physical chunk ^ swizzle(row)), the read side applies the same involution.
+// (`part` of `nparts`: the copies i = part, part + nparts, ... only -- for spreading the issue over the MFMA groups)
 template <int ROWS, int NT>
-TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, u32x4* tile, int t, int wave) {
+TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, u32x4* tile, int t, int wave,
+                         int part = 0, int nparts = 1) {
 #pragma unroll
     for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        if (i % nparts != part) continue;
         const int idx = t + i * NT, row = idx >> 3;
         const int logical = tg_swz(row, idx & 7);                 // involution: logical = physical ^ s(row)
         tg_glds16(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
@@ -228,16 +241,35 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     TgKTile<GE::TN, GE::NT> breg;
     const size_t bpitch = (size_t)a.nsteps * 128;
 
-    auto load_stage = [&](int step) {
+    auto load_m = [&](int step, int j) {                       // one float4 row of the M micro-block of `step`
+        const int c = step * PR::BKE + kc * PR::CH + half * RS + j;
+        const int cc = c < a.C ? c : a.C - 1;
+        mreg[j] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + vload);
+    };
+    auto load_sh = [&](int step) {
         const int cb = step * PR::BKE + kc * PR::CH + half * RS;
 #pragma unroll
-        for (int j = 0; j < RS; ++j) {
-            const int c = cb + j;
-            const int cc = c < a.C ? c : a.C - 1;
-            mreg[j] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + vload);
-            sh[j] = a.rlse2[c];
-        }
+        for (int j = 0; j < RS; ++j) sh[j] = a.rlse2[cb + j];
+    };
+    auto load_stage = [&](int step) {
+#pragma unroll
+        for (int j = 0; j < RS; ++j) load_m(step, j);
+        load_sh(step);
         if (!TG_GLDS) breg.load(a.St, (size_t)k0, bpitch, (size_t)step, t);
+    };
+    // the same global loads + the LDS-DMA of S^T as NITEM separate issues, spread over the first NSPREAD MFMA groups
+    constexpr int GA_F = (PR::NP == 2 ? 1 : 2);                // the M staging registers leave room for small blocks only
+    constexpr int NG_F = TgMmaShape<PR, GE, GA_F>::NG;
+    constexpr int NSPREAD = (NG_F * 3) / 4 > 0 ? (NG_F * 3) / 4 : 1;
+    constexpr int NITEM = GE::LB + RS + 1;
+    auto issue_next = [&](int step, u32x4* st, int i) {
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            if ((k * NSPREAD) / NITEM != i) continue;
+            if (k < RS) load_m(step, k);
+            else if (k == RS) load_sh(step);
+            else tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)step, st + GE::A_CHUNKS, t, wave, k - RS - 1, GE::LB);
+        }
     };
     auto store_stage = [&](u32x4* st) {
 #pragma unroll
@@ -275,11 +307,16 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s - s_begin + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < s_end;
-            if (more) {                             // global loads / LDS-DMA in flight under the MFMAs
-                if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
-                load_stage(s + 1);
+            if (TG_GLDS && PR::NP == 2) {           // next step's global loads / LDS-DMA trickle in between the MFMA groups
+                                                    // (bf16x3: -2 %; slower for the 8-row micro-blocks of bf16, profiles/r01/run26)
+                tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [&](int i) { if (more) issue_next(s + 1, nxt, i); });
+            } else {
+                if (more) {
+                    if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
+                    load_stage(s + 1);
+                }
+                tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [](int) {});
             }
-            tg_tile_mma<PR, GE, (PR::NP == 2 ? 1 : 2)>(cur, wm, wn, lane, acc);    // the M staging registers leave room for small blocks only
             if (more) store_stage(nxt);
             __syncthreads();
         }
@@ -625,11 +662,17 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
         for (int s = 0; s < nsteps; ++s) {
             u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
-            if ((s + 1) < nsteps) {                 // DMA of the next step lands while the matrix cores run
-                tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, (size_t)(s + 1), nxt, t, wave);
-                tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
-            }
-            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
+            const bool more = (s + 1) < nsteps;     // DMA of the next step lands while the matrix cores run, issued a few
+            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [&](int i) {     // copies per MFMA group (see tg_tile_mma)
+                constexpr int NG_B = TgMmaShape<PR, GE>::NG, NSP = (NG_B * 3) / 4 > 0 ? (NG_B * 3) / 4 : 1, NIT = GE::LA + GE::LB;
+                if (!more) return;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    if ((k * NSP) / NIT != i) continue;
+                    if (k < GE::LA) tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, (size_t)(s + 1), nxt, t, wave, k, GE::LA);
+                    else tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave, k - GE::LA, GE::LB);
+                }
+            });
             __syncthreads();                        // drains the DMA (vmcnt) and releases `cur` for the step after next
         }
 #else
@@ -648,7 +691,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
                 ra.load(a.dG, (size_t)v0, pitch, (size_t)(s + 1), t);
                 rb.load(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), t);
             }
-            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc);
+            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [](int) {});
             if (more) { ra.store(nxt, t); rb.store(nxt + GE::A_CHUNKS, t); }
             __syncthreads();
         }
