@@ -702,21 +702,40 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     if constexpr (!ROWDOT) {
         // single-GPU schedule: only X = S dGhat^T leaves the kernel; the row dots are taken by tg_adam_rowpass, which
         // holds a whole row of M and X in registers (saves the M read, the exponentials and the partial-sum traffic here)
+        // The MFMA result layout gives a lane 4 consecutive spots of ONE cell (16 cells per wave instruction), i.e. 16 separate
+        // 64-byte pieces per store: ~13 us per tile, not overlapped with anything (one workgroup per CU).  The tile is
+        // therefore transposed through the (now idle) LDS in NPASS passes and leaves as full 1 KB row segments.
+        constexpr int RC = GE::TM / 4;                                        // 16-byte columns of a staged row (one cell, TM spots)
+        constexpr int CPP = (GE::LDS_BYTES / (GE::TM * 4) < GE::TN) ? GE::LDS_BYTES / (GE::TM * 4) : GE::TN;   // cells per pass
+        constexpr int NPASS = GE::TN / CPP, FPP = GE::FN / NPASS;             // passes, cell fragments per wave and pass
+        static_assert(FPP * NPASS == GE::FN && CPP == GE::WN * FPP * 16 && (CPP * RC) % GE::NT == 0 && RC >= 16, "epilogue staging geometry");
+        f32x4* stg = (f32x4*)tg_lds;
         const int g = lane >> 4, r15 = lane & 15;
-        const int vbase = v0 + wm * (GE::TM / GE::WM) + 4 * g;
 #pragma unroll
-        for (int fj = 0; fj < GE::FN; ++fj) {
-            const int c = c0 + wn * (GE::TN / GE::WN) + fj * 16 + r15;
-            if (c >= a.C) continue;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (pass) __syncthreads();                                        // the previous pass has been read out
 #pragma unroll
-            for (int fi = 0; fi < GE::FM; ++fi) {
-                const int v = vbase + fi * 16;
-                if (v >= a.Vp) continue;
+            for (int fjl = 0; fjl < FPP; ++fjl) {
+                const int cell_l = (wn * FPP + fjl) * 16 + r15;
+#pragma unroll
+                for (int fi = 0; fi < GE::FM; ++fi) {
+                    const int col = (wm * (GE::TM / GE::WM) + fi * 16) / 4 + g;
+                    stg[cell_l * RC + (col ^ r15)] = acc[fi][pass * FPP + fjl];   // XOR swizzle: the 16 cells of a lane group hit 16 different columns
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < (CPP * RC) / GE::NT; ++it) {
+                const int idx = it * GE::NT + t, row = idx / RC, j = idx % RC;
+                const int wn_r = row / (FPP * 16), rem = row % (FPP * 16);
+                const int c = c0 + wn_r * (GE::TN / GE::WN) + (pass * FPP + rem / 16) * 16 + (rem & 15);
+                const int v = v0 + 4 * j;
+                if (c >= a.C || v >= a.Vp) continue;
+                const f32x4 x = stg[row * RC + (j ^ (row & 15))];
                 if constexpr (PR::X16)
-                    *(u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v) =
-                        u32x2{tg_pack_bf16(acc[fi][fj][0], acc[fi][fj][1]), tg_pack_bf16(acc[fi][fj][2], acc[fi][fj][3])};
+                    *(u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v) = u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])};
                 else
-                    *(f32x4*)((float*)a.X + (size_t)c * a.Vp + v) = acc[fi][fj];
+                    *(f32x4*)((float*)a.X + (size_t)c * a.Vp + v) = x;
             }
         }
         return;
