@@ -351,7 +351,7 @@ static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
         TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
         const int nrb = (L.V + TG_RB - 1) / TG_RB;
         TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_WG), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
-        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_wgn2));
+        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_wgn2));
         TG_CK(tg_check_launch());
     }
     return TG_OK;
@@ -367,7 +367,7 @@ static int tg_launch_spatial_stats(tg_mapper* m) {
         TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
         const int nrb = (L.V + TG_RB - 1) / TG_RB;
         TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_Y), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
-        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_nbstat));
+        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_nbstat));
         tg_prof_mark(m, "tg_spatial_nb_stats");
     }
     if (L.has_ct) {
@@ -420,9 +420,9 @@ static int tg_setup_autocorr(tg_mapper* m) {
     TG_LAUNCH(tg_ac_refs, nrb, 1, 256, 0, m->stream, a);
     // |Tg_k|^2 and |Tm_k|^2 (rows 0 and 2 of tnorm)
     TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tg, (const float*)a.Tg, L.V, L.Kp, a.part);
-    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm));
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm));
     TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tm, (const float*)a.Tm, L.V, L.Kp, a.part);
-    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm) + 2 * (size_t)L.Kp);
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm) + 2 * (size_t)L.Kp);
     TG_CK(tg_check_launch());
     return TG_OK;
 }
@@ -604,7 +604,7 @@ static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
     TG_LAUNCH(tg_ghat_reduce, nrb, 1, 256, 4 * TG_RB * 2 * 4, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
-    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 256, 4 * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
               m->fp(L.o_genestat));
     tg_prof_mark(m, "tg_gene_reduce");
     return TG_OK;
@@ -628,7 +628,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
     int rcs = tg_launch_spatial_stats(m);
     if (rcs) return rcs;
-    TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 64, m->stream, f);
+    TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 16 * 5 * 4, m->stream, f);
     tg_prof_mark(m, "tg_loss_finalize");
     if ((rcs = tg_launch_spatial_grad(m))) return rcs;
     if (L.has_ac && (rcs = tg_launch_autocorr(m, hist_row))) return rcs;

@@ -403,22 +403,24 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) {
     }
 }
 
-// K2b: second stage of the per-gene sums (fixed order => deterministic): 64 genes x 4 partial groups per block
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
+// K2b: second stage of the per-gene sums (fixed order => deterministic): 64 genes x 16 partial groups per block.
+// (A latency-bound kernel: every thread walks nrb / 16 row blocks; with 4 groups it took 29 us at 600 row blocks.)
+#define TG_GR_GROUPS 16
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
     TG_LDS_DECL;
-    float* red = (float*)tg_lds;        // [4][64][2]
+    float* red = (float*)tg_lds;        // [TG_GR_GROUPS][64][2]
     const int kx = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kx;
     float d0 = 0.f, n0 = 0.f, d1 = 0.f, n1 = 0.f;
     if (k < Kp) {
         int b = grp;
-        for (; b + 4 < nrb; b += 8) {
+        for (; b + TG_GR_GROUPS < nrb; b += 2 * TG_GR_GROUPS) {
             d0 += genepart[((size_t)b * 2 + 0) * Kp + k];
             n0 += genepart[((size_t)b * 2 + 1) * Kp + k];
-            d1 += genepart[((size_t)(b + 4) * 2 + 0) * Kp + k];
-            n1 += genepart[((size_t)(b + 4) * 2 + 1) * Kp + k];
+            d1 += genepart[((size_t)(b + TG_GR_GROUPS) * 2 + 0) * Kp + k];
+            n1 += genepart[((size_t)(b + TG_GR_GROUPS) * 2 + 1) * Kp + k];
         }
-        for (; b < nrb; b += 4) {
+        for (; b < nrb; b += TG_GR_GROUPS) {
             d0 += genepart[((size_t)b * 2 + 0) * Kp + k];
             n0 += genepart[((size_t)b * 2 + 1) * Kp + k];
         }
@@ -428,7 +430,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_gene_reduce(const float* genepart, int n
     __syncthreads();
     if (grp == 0 && k < Kp) {
         float d = 0.f, n = 0.f;
-        for (int g = 0; g < 4; ++g) { d += red[(g * 64 + kx) * 2 + 0]; n += red[(g * 64 + kx) * 2 + 1]; }
+        for (int g = 0; g < TG_GR_GROUPS; ++g) { d += red[(g * 64 + kx) * 2 + 0]; n += red[(g * 64 + kx) * 2 + 1]; }
         genestat[k] = d;
         genestat[Kp + k] = n;
     }
@@ -477,6 +479,27 @@ TG_DEV float tg_block_sum_1024(float x, float* red) {
     for (int w = 0; w < nw; ++w) s += red[w];
     return s;
 }
+// N block sums with ONE pair of barriers (same fixed summation order as N calls of tg_block_sum_1024)
+template <int N>
+TG_DEV void tg_block_sums_1024(float (&x)[N], float* red) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x[i] += tg_shfl_xor(x[i], m);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[wave * N + i] = x[i];
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w * N + i];
+        x[i] = s;
+    }
+}
 
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
     TG_LDS_DECL;
@@ -498,7 +521,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
         a.coef[k] = al;
         a.coef[a.Kp + k] = be;
     }
-    const float gv = tg_block_sum_1024(cs, red) / (float)a.K;
     float nbs = 0.f;
     if (a.nbstat) {
         for (int k = t; k < a.Kp; k += 1024) {
@@ -517,40 +539,54 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
             a.nbcoef[a.Kp + k] = be;
         }
     }
-    const float nbv = tg_block_sum_1024(nbs, red) / (float)a.K;
     float cts = 0.f;
     if (a.ctpart) for (int i = t; i < a.n_ctpart; i += 1024) cts += a.ctpart[i];
-    const float isl = tg_block_sum_1024(cts, red) / ((float)a.V * (float)(a.T > 0 ? a.T : 1));
-
     float vs = 0.f, kl = 0.f;
     const float rho_scale = a.fsum_dev ? 1.f / a.fsum_dev[0] : a.rho_scale;
-    for (int v = t; v < a.Vr; v += 1024) {
-        float va = 0.f, vb = 0.f, av = 0.f;
-        if (v < a.V) {
-            if (a.lambda_g2 != 0.f) {
-                const float dot = a.voxstat[v];
-                const float na = tg_fmax(sqrtf(a.voxstat[a.Vr + v]), TG_COS_EPS);
-                const float nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
-                const float c = dot / (na * nb);
-                vs += c;
-                const float w = a.lambda_g2 / (float)a.V_total;
-                va = -w / (na * nb);
-                vb = w * c / (na * na);
-            }
-            if (a.has_density) {
-                const float colsum = a.Ghat[(size_t)v * a.Kp + a.K];
-                const float dv = a.d[v];
-                const float rho = colsum * rho_scale;
-                if (dv != 0.f) kl += dv * (tg_log(dv) - tg_log(rho));   // KLDivLoss(sum): xlogy(d,d) - d*log(rho)
-                av = -a.lambda_d * dv * rho_scale / rho;                // = -lambda_d d_v / colsum_v
-            }
+    // (4 spots per trip with all their loads issued first: this single-workgroup loop is pure memory latency)
+    for (int vb0 = t; vb0 < a.Vr; vb0 += 4 * 1024) {
+        float dot[4], n2a[4], n2b[4], colsum[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = vb0 + u * 1024;
+            const bool in = v < a.V;
+            dot[u] = (in && a.lambda_g2 != 0.f) ? a.voxstat[v] : 0.f;
+            n2a[u] = (in && a.lambda_g2 != 0.f) ? a.voxstat[a.Vr + v] : 1.f;
+            n2b[u] = (in && a.lambda_g2 != 0.f) ? a.vnorm2[v] : 1.f;
+            colsum[u] = (in && a.has_density) ? a.Ghat[(size_t)v * a.Kp + a.K] : 1.f;
+            dv[u] = (in && a.has_density) ? a.d[v] : 0.f;
         }
-        a.vcoef[v] = va;
-        a.vcoef[a.Vr + v] = vb;
-        a.vcoef[2 * a.Vr + v] = av;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = vb0 + u * 1024;
+            if (v >= a.Vr) continue;
+            float va = 0.f, vb = 0.f, av = 0.f;
+            if (v < a.V) {
+                if (a.lambda_g2 != 0.f) {
+                    const float na = tg_fmax(sqrtf(n2a[u]), TG_COS_EPS);
+                    const float nb = tg_fmax(sqrtf(n2b[u]), TG_COS_EPS);
+                    const float c = dot[u] / (na * nb);
+                    vs += c;
+                    const float w = a.lambda_g2 / (float)a.V_total;
+                    va = -w / (na * nb);
+                    vb = w * c / (na * na);
+                }
+                if (a.has_density) {
+                    const float rho = colsum[u] * rho_scale;
+                    if (dv[u] != 0.f) kl += dv[u] * (tg_log(dv[u]) - tg_log(rho));   // KLDivLoss(sum): xlogy(d,d) - d*log(rho)
+                    av = -a.lambda_d * dv[u] * rho_scale / rho;                      // = -lambda_d d_v / colsum_v
+                }
+            }
+            a.vcoef[v] = va;
+            a.vcoef[a.Vr + v] = vb;
+            a.vcoef[2 * a.Vr + v] = av;
+        }
     }
-    const float vg = tg_block_sum_1024(vs, red) / (float)a.V_total;
-    const float klsum = tg_block_sum_1024(kl, red);
+    float sums[5] = {cs, nbs, cts, vs, kl};           // the five scalars share one block reduction
+    tg_block_sums_1024(sums, red);
+    const float gv = sums[0] / (float)a.K, nbv = sums[1] / (float)a.K;
+    const float isl = sums[2] / ((float)a.V * (float)(a.T > 0 ? a.T : 1));
+    const float vg = sums[3] / (float)a.V_total, klsum = sums[4];
     if (t == 0) {
         const float nanv = __builtin_nanf("");
         float total = -a.lambda_g1 * gv;
