@@ -158,7 +158,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_genepart = take((size_t)L->nrb * 2 * L->Kp * 4);
     L->o_genestat = take((size_t)2 * L->Kp * 4);
     L->o_gnorm2 = take((size_t)L->Kp * 4);
-    L->o_voxstat = take((size_t)2 * L->Vr * 4);
+    L->o_voxstat = take((size_t)((L->Kp + TG_GH_COLS - 1) / TG_GH_COLS) * 2 * L->Vr * 4);
     L->o_vnorm2 = take((size_t)L->Vr * 4);
     L->o_d = take((size_t)L->Vr * 4);
     L->o_coef = take((size_t)2 * L->Kp * 4);
@@ -602,7 +602,7 @@ static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
     a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat);
     a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = force_vox || (m->cfg.lambda_g2 != 0.f);
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
-    TG_LAUNCH(tg_ghat_reduce, nrb, 1, 256, 4 * TG_RB * 2 * 4, m->stream, a);
+    TG_LAUNCH(tg_ghat_reduce, nrb, (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS, 256, 4 * 64 * 2 * 16, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
     TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
               m->fp(L.o_genestat));
@@ -615,7 +615,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
     TgFinalizeArgs f;
     f.genestat = m->fp(L.o_genestat); f.gnorm2 = m->fp(L.o_gnorm2); f.Ghat = m->fp(L.o_Ghat);
-    f.voxstat = m->fp(L.o_voxstat); f.vnorm2 = m->fp(L.o_vnorm2); f.d = m->fp(L.o_d);
+    f.voxstat = m->fp(L.o_voxstat); f.nky = (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS; f.vnorm2 = m->fp(L.o_vnorm2); f.d = m->fp(L.o_d);
     f.coef = m->fp(L.o_coef); f.vcoef = m->fp(L.o_vcoef);
     f.hist = hist_row ? hist_row : m->fp(L.o_scal);
     f.lambda_g1 = m->cfg.lambda_g1; f.lambda_g2 = m->cfg.lambda_g2; f.lambda_d = m->cfg.lambda_d;
@@ -995,7 +995,7 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
               (const float*)m->fp(L.o_rinvz), L.V, L.Vp, m->fp(L.o_rowent));
     TgValArgs a;
     a.genestat = m->fp(L.o_genestat); a.gnorm2 = m->fp(L.o_gnorm2); a.gfrac = m->fp(L.o_gfrac);
-    a.voxstat = m->fp(L.o_voxstat); a.vnorm2 = m->fp(L.o_vnorm2); a.rowent = m->fp(L.o_rowent);
+    a.voxstat = m->fp(L.o_voxstat); a.nky = (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS; a.vnorm2 = m->fp(L.o_vnorm2); a.rowent = m->fp(L.o_rowent);
     a.out = out4_dev; a.K = L.K; a.Kp = L.Kp; a.V = L.V; a.Vr = L.Vr; a.C = L.C;
     TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);
     TG_CK(tg_check_launch());

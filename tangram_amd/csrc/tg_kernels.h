@@ -347,58 +347,61 @@ struct TgGhatReduceArgs {
     const float* G;            // [Vr][Kp] fp32, zero padded
     float* Ghat;               // [Vr][Kp]
     float* genepart;           // [nrb][2][Kp]  (dot, |Ghat|^2)
-    float* voxstat;            // [2][Vr] (dot_v, |Ghat_v|^2) over genes k < K; written iff want_vox
+    float* voxstat;            // [nky][2][Vr] (dot_v, |Ghat_v|^2) over the genes k < K of column block ky; written iff want_vox
     int V, Vr, Kp, K, want_vox;
 };
+#define TG_GH_COLS 256         // gene columns per workgroup: grid = (row blocks of TG_RB spots, ceil(Kp / TG_GH_COLS))
 
+// One workgroup = 16 spots x 256 genes: wave w owns 4 of the spot rows, lane q one float4 of genes.  (The earlier layout,
+// 16 rows x all genes per workgroup, left a V = 1250 spot shard with 79 workgroups to stream 12 partial copies of Ghat.)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) {
     TG_LDS_DECL;
-    float* red = (float*)tg_lds;     // [4 waves][TG_RB][2]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int rb = blockIdx.x;
-    const int vbeg = rb * TG_RB;
-    const int nk4 = a.Kp >> 2;
-    float vd[TG_RB], vn[TG_RB];
+    f32x4* red = (f32x4*)tg_lds;     // [4 row groups][64 lanes][2]
+    const int t = threadIdx.x, q = t & 63, rg = t >> 6;
+    const int rb = blockIdx.x, ky = blockIdx.y;
+    const int vbeg = rb * TG_RB + rg * (TG_RB / 4);
+    const int k = ky * TG_GH_COLS + 4 * q;
+    const bool kok = k < a.Kp;
+    f32x4 gd = {0, 0, 0, 0}, gn = {0, 0, 0, 0};
+    float vd[TG_RB / 4], vn[TG_RB / 4];
 #pragma unroll
-    for (int i = 0; i < TG_RB; ++i) vd[i] = vn[i] = 0.f;
-    for (int c4 = t; c4 < nk4; c4 += 256) {
-        f32x4 gd = {0, 0, 0, 0}, gn = {0, 0, 0, 0};
-        const int k = c4 * 4;
+    for (int i = 0; i < TG_RB / 4; ++i) {
+        vd[i] = vn[i] = 0.f;
+        const int v = vbeg + i;
+        if (kok && v < a.V) {
+            const size_t off = (size_t)v * a.Kp + k;
+            f32x4 s = *(const f32x4*)(a.Gpart + off);
+            for (int p = 1; p < a.nsplit; ++p) s += *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
+            *(f32x4*)(a.Ghat + off) = s;
+            const f32x4 g = *(const f32x4*)(a.G + off);
+            gd += s * g;
+            gn += s * s;
+            if (a.want_vox) {
 #pragma unroll
-        for (int i = 0; i < TG_RB; ++i) {
-            const int v = vbeg + i;
-            if (v < a.V) {
-                const size_t off = (size_t)v * a.Kp + k;
-                f32x4 s = *(const f32x4*)(a.Gpart + off);
-                for (int p = 1; p < a.nsplit; ++p) s += *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
-                *(f32x4*)(a.Ghat + off) = s;
-                const f32x4 g = *(const f32x4*)(a.G + off);
-                gd += s * g;
-                gn += s * s;
-                if (a.want_vox) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (k + e < a.K) { vd[i] += s[e] * g[e]; vn[i] += s[e] * s[e]; }
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < a.K) { vd[i] += s[e] * g[e]; vn[i] += s[e] * s[e]; }
             }
         }
+    }
+    red[(rg * 64 + q) * 2 + 0] = gd;
+    red[(rg * 64 + q) * 2 + 1] = gn;
+    __syncthreads();
+    if (rg == 0 && kok) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r) { gd += red[(r * 64 + q) * 2 + 0]; gn += red[(r * 64 + q) * 2 + 1]; }
         *(f32x4*)(a.genepart + ((size_t)rb * 2 + 0) * a.Kp + k) = gd;
         *(f32x4*)(a.genepart + ((size_t)rb * 2 + 1) * a.Kp + k) = gn;
     }
     if (a.want_vox) {
 #pragma unroll
-        for (int i = 0; i < TG_RB; ++i) {
+        for (int i = 0; i < TG_RB / 4; ++i) {
             float d = vd[i], n = vn[i];
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { d += tg_shfl_xor(d, m); n += tg_shfl_xor(n, m); }
-            if (lane == 0) { red[(wave * TG_RB + i) * 2 + 0] = d; red[(wave * TG_RB + i) * 2 + 1] = n; }
-        }
-        __syncthreads();
-        if (t < TG_RB && vbeg + t < a.V) {
-            float d = 0.f, n = 0.f;
-            for (int w = 0; w < 4; ++w) { d += red[(w * TG_RB + t) * 2 + 0]; n += red[(w * TG_RB + t) * 2 + 1]; }
-            a.voxstat[vbeg + t] = d;
-            a.voxstat[a.Vr + vbeg + t] = n;
+            if (q == 0 && vbeg + i < a.V) {
+                a.voxstat[((size_t)ky * 2 + 0) * a.Vr + vbeg + i] = d;
+                a.voxstat[((size_t)ky * 2 + 1) * a.Vr + vbeg + i] = n;
+            }
         }
     }
 }
@@ -449,7 +452,8 @@ struct TgFinalizeArgs {
     const float* genestat;     // [2][Kp] (dot_k, |Ghat_k|^2) (global)
     const float* gnorm2;       // [Kp] |G_k|^2 (global)
     const float* Ghat;         // [Vr][Kp] (aug column K = colsum)
-    const float* voxstat;      // [2][Vr]
+    const float* voxstat;      // [nky][2][Vr] partial over gene column blocks
+    int nky;
     const float* vnorm2;       // [Vr] |G_v|^2 over genes
     const float* d;            // [Vr] density prior or null
     float* coef;               // [2][Kp] alpha, beta
@@ -550,8 +554,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
         for (int u = 0; u < 4; ++u) {
             const int v = vb0 + u * 1024;
             const bool in = v < a.V;
-            dot[u] = (in && a.lambda_g2 != 0.f) ? a.voxstat[v] : 0.f;
-            n2a[u] = (in && a.lambda_g2 != 0.f) ? a.voxstat[a.Vr + v] : 1.f;
+            dot[u] = 0.f; n2a[u] = (in && a.lambda_g2 != 0.f) ? 0.f : 1.f;
+            if (in && a.lambda_g2 != 0.f)
+                for (int y = 0; y < a.nky; ++y) { dot[u] += a.voxstat[((size_t)y * 2 + 0) * a.Vr + v]; n2a[u] += a.voxstat[((size_t)y * 2 + 1) * a.Vr + v]; }
             n2b[u] = (in && a.lambda_g2 != 0.f) ? a.vnorm2[v] : 1.f;
             colsum[u] = (in && a.has_density) ? a.Ghat[(size_t)v * a.Kp + a.K] : 1.f;
             dv[u] = (in && a.has_density) ? a.d[v] : 0.f;
@@ -1600,7 +1605,7 @@ struct TgValArgs {
     const float* genestat; const float* gnorm2; const float* gfrac;     // [2][Kp], [Kp], [Kp] (fraction of non-zero spots per gene)
     const float* voxstat; const float* vnorm2; const float* rowent;
     float* out;                                                          // [4]: gv + vg, gv, sparsity-weighted gv, entropy
-    int K, Kp, V, Vr, C;
+    int K, Kp, V, Vr, C, nky;
 };
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_val_finalize(TgValArgs a) {
     TG_LDS_DECL;
@@ -1618,8 +1623,10 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_val_finalize(TgValArgs a) {
     const float wsum = tg_block_sum_1024(ws, red), wnorm = tg_block_sum_1024(wn, red);
     float vs = 0.f;
     for (int v = t; v < a.V; v += 1024) {
-        const float na = tg_fmax(sqrtf(a.voxstat[a.Vr + v]), TG_COS_EPS), nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
-        vs += a.voxstat[v] / (na * nb);
+        float dot = 0.f, n2 = 0.f;
+        for (int y = 0; y < a.nky; ++y) { dot += a.voxstat[((size_t)y * 2 + 0) * a.Vr + v]; n2 += a.voxstat[((size_t)y * 2 + 1) * a.Vr + v]; }
+        const float na = tg_fmax(sqrtf(n2), TG_COS_EPS), nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
+        vs += dot / (na * nb);
     }
     const float vg = tg_block_sum_1024(vs, red) / (float)a.V;
     float es = 0.f;
