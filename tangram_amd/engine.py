@@ -119,8 +119,8 @@ class HipMapperEngine:
         self.state = torch.empty(sizes.state_bytes, dtype=torch.uint8, device=self.device)
         self.workspace = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
         handle = ct.c_void_p()
-        _capi.check(self._lib.tg_mapper_create(ct.byref(cfg), ct.byref(inp), self.state.data_ptr(),
-                                               self.workspace.data_ptr(), self._stream(), ct.byref(handle)))
+        self._call(self._lib.tg_mapper_create, ct.byref(cfg), ct.byref(inp), self.state.data_ptr(),
+                   self.workspace.data_ptr(), self._stream(), ct.byref(handle))
         self._h = handle
         self._sync()            # inputs were only borrowed for the duration of create()
         self._scratch_row = torch.zeros(_capi.H_NTERMS, dtype=torch.float32, device=self.device)
@@ -134,6 +134,14 @@ class HipMapperEngine:
     def _sync(self):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+
+    def _call(self, fn, *args):
+        """One C-ABI call with this mapper's GPU as the current HIP device (the library enqueues on the stream it was created
+        with; HIP rejects a stream that does not belong to the current device)."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != (self.device.index or 0):
+            with torch.cuda.device(self.device):
+                return _capi.check(fn(*args))
+        return _capi.check(fn(*args))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -153,29 +161,29 @@ class HipMapperEngine:
 
     def step(self, n_steps, lr, history=None, first_row=0):
         hp = history.data_ptr() if history is not None else None
-        _capi.check(self._lib.tg_mapper_step(self._h, int(n_steps), float(lr), hp, int(first_row)))
+        self._call(self._lib.tg_mapper_step, self._h, int(n_steps), float(lr), hp, int(first_row))
 
     def phase(self, phase, lr=0.0, history_row=None, gathered=None, nranks=0):
         hp = history_row.data_ptr() if history_row is not None else None
         gp = gathered.data_ptr() if gathered is not None else None
-        _capi.check(self._lib.tg_mapper_phase(self._h, int(phase), float(lr), hp, gp, int(nranks)))
+        self._call(self._lib.tg_mapper_phase, self._h, int(phase), float(lr), hp, gp, int(nranks))
 
     def exchange_buffer(self, which):
         """A float32 torch view (no copy) of one of the cross-GPU exchange vectors inside the workspace."""
         p, n = ct.c_void_p(), ct.c_size_t()
-        _capi.check(self._lib.tg_mapper_exchange_buffer(self._h, int(which), ct.byref(p), ct.byref(n)))
+        self._call(self._lib.tg_mapper_exchange_buffer, self._h, int(which), ct.byref(p), ct.byref(n))
         off = p.value - self.workspace.data_ptr()
         return self.workspace[off:off + 4 * n.value].view(torch.float32)
 
     def result(self, with_filter=False):
         P = torch.empty((self.C, self.V), dtype=torch.float32, device=self.device)
         F = torch.empty((self.C,), dtype=torch.float32, device=self.device) if with_filter else None
-        _capi.check(self._lib.tg_mapper_result(self._h, P.data_ptr(), F.data_ptr() if with_filter else None))
+        self._call(self._lib.tg_mapper_result, self._h, P.data_ptr(), F.data_ptr() if with_filter else None)
         return (P, F) if with_filter else P
 
     def project(self):
         Gh = torch.empty((self.V, self.K), dtype=torch.float32, device=self.device)
-        _capi.check(self._lib.tg_mapper_project(self._h, Gh.data_ptr()))
+        self._call(self._lib.tg_mapper_project, self._h, Gh.data_ptr())
         return Gh
 
     def project_genes(self, S_all, unfiltered=True):
@@ -189,22 +197,22 @@ class HipMapperEngine:
             S_all = S_all.contiguous()
         n = int(S_all.shape[1])
         out = torch.empty((self.V, n), dtype=torch.float32, device=self.device)
-        _capi.check(self._lib.tg_mapper_project_genes(self._h, S_all.data_ptr(), int(S_all.stride(0)), n, out.data_ptr(), n,
-                                                      1 if unfiltered else 0))
+        self._call(self._lib.tg_mapper_project_genes, self._h, S_all.data_ptr(), int(S_all.stride(0)), n, out.data_ptr(), n,
+                   1 if unfiltered else 0)
         return out
 
     def validate(self):
         """(expression_sim, gv_sim, sparsity-weighted gv_sim, entropy) of the current mapping; one D2H copy."""
         out = torch.empty(4, dtype=torch.float32, device=self.device)
-        _capi.check(self._lib.tg_mapper_validate(self._h, out.data_ptr()))
+        self._call(self._lib.tg_mapper_validate, self._h, out.data_ptr())
         return [float(x) for x in out.cpu().numpy()]
 
     def logits(self):
         """Views of M / Adam m / Adam v ([C, pitch] float32, columns >= V are padding)."""
         pm, p1, p2 = ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
         pitch, step = ct.c_int32(), ct.c_int64()
-        _capi.check(self._lib.tg_mapper_state(self._h, ct.byref(pm), ct.byref(p1), ct.byref(p2), ct.byref(pitch),
-                                              ct.byref(step)))
+        self._call(self._lib.tg_mapper_state, self._h, ct.byref(pm), ct.byref(p1), ct.byref(p2), ct.byref(pitch),
+                                              ct.byref(step))
         out = []
         for p in (pm, p1, p2):
             off = p.value - self.state.data_ptr()
@@ -212,10 +220,10 @@ class HipMapperEngine:
         return out[0], out[1], out[2], int(step.value)
 
     def set_step(self, step):
-        _capi.check(self._lib.tg_mapper_set_step(self._h, int(step)))
+        self._call(self._lib.tg_mapper_set_step, self._h, int(step))
 
     def profile(self, enable=True):
-        _capi.check(self._lib.tg_mapper_profile(self._h, int(bool(enable))))
+        self._call(self._lib.tg_mapper_profile, self._h, int(bool(enable)))
 
     def profile_read(self):
         """[(kernel name, total ms, launches)] since profile(True); synchronises the stream."""
@@ -223,6 +231,6 @@ class HipMapperEngine:
         ms = (ct.c_float * 64)()
         cnt = (ct.c_int * 64)()
         n = ct.c_int()
-        _capi.check(self._lib.tg_mapper_profile_read(self._h, names, 4096, ms, cnt, 64, ct.byref(n)))
+        self._call(self._lib.tg_mapper_profile_read, self._h, names, 4096, ms, cnt, 64, ct.byref(n))
         ks = names.value.decode().split(";") if n.value else []
         return [(k, float(ms[i]), int(cnt[i])) for i, k in enumerate(ks)]
