@@ -44,6 +44,8 @@ class HipMapperEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda" and not _capi.is_emulated():
             raise RuntimeError(f"tangram_amd runs on a HIP device only (got device={device!r}); there is no CPU path")
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if precision not in _capi.PRECISIONS:
             raise ValueError(f"gemm precision must be one of {sorted(_capi.PRECISIONS)}")
         self._lib = _capi.lib()
@@ -138,7 +140,7 @@ class HipMapperEngine:
     def _call(self, fn, *args):
         """One C-ABI call with this mapper's GPU as the current HIP device (the library enqueues on the stream it was created
         with; HIP rejects a stream that does not belong to the current device)."""
-        if self.device.type == "cuda" and torch.cuda.current_device() != (self.device.index or 0):
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
             with torch.cuda.device(self.device):
                 return _capi.check(fn(*args))
         return _capi.check(fn(*args))
