@@ -43,7 +43,20 @@ CASES = {
     "constrained_entropy": (90, 30, 50, 8, 30, "constrained",
                             dict(lambda_d=1, lambda_g1=1, lambda_g2=0.3, lambda_r=1e-3, lambda_count=0.5,
                                  lambda_f_reg=2.0, target_count=30)),
+    # The parameter grid of the reference's own tests (tests/tangram_test.py:67-103 and :159-170): mode='clusters', 500 epochs,
+    # random_state=42, (lambda_g2, lambda_d, density_prior, scale) varied.  In clusters mode map_cells_to_space forces
+    # lambda_d >= 1 and falls back to the uniform prior (mapping_utils.py:293-307), so the 9 + 6 rows of the reference grid
+    # collapse to these 7 distinct optimizer configurations.  Their data files are missing from the checkout, so the cells
+    # are synthetic; the cluster aggregation (sum if scale else mean, densities = cell fractions) follows :103-139.
+    "grid_g2_0_d1_uniform_scaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=0, lambda_d=1, prior="uniform", scale=True)),
+    "grid_g2_0_d1_uniform_unscaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=0, lambda_d=1, prior="uniform", scale=False)),
+    "grid_g2_1_d1_uniform_scaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=1, lambda_d=1, prior="uniform", scale=True)),
+    "grid_g2_1_d1_uniform_unscaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=1, lambda_d=1, prior="uniform", scale=False)),
+    "grid_g2_0_d2_uniform_scaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=0, lambda_d=2, prior="uniform", scale=True)),
+    "grid_g2_0_d1_rna_scaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=0, lambda_d=1, prior="rna_count_based", scale=True)),
+    "grid_g2_0_d1_rna_unscaled": (12, 60, 80, 11, 500, "grid", dict(lambda_g1=1, lambda_g2=0, lambda_d=1, prior="rna_count_based", scale=False)),
 }
+GRID_CELLS = 360
 RANDOM_STATE = 42
 
 
@@ -54,9 +67,34 @@ def load_ref():
     return mo
 
 
+def cluster_inputs(n_clusters, K, V, seed, scale, prior):
+    """Cell-level synthetic data aggregated like adata_to_cluster_expression (mapping_utils.py:103-139) + the density priors
+    of pp_adatas (:88-94).  Returns S [clusters, K], G, d, d_source and the cell-level pieces (for the wrapper-level tests)."""
+    data = make_synthetic(GRID_CELLS, K, V, seed=seed)
+    rng = np.random.default_rng(seed + 7)
+    sizes = GRID_CELLS // n_clusters - (n_clusters - 1) + 2 * np.arange(n_clusters)      # all different: no ties in value_counts
+    sizes[-1] += GRID_CELLS - sizes.sum()
+    labels = np.repeat(np.arange(n_clusters), sizes)
+    rng.shuffle(labels)
+    counts = np.bincount(labels, minlength=n_clusters)
+    order = np.argsort(-counts, kind="stable")                    # value_counts order: most frequent first
+    S_cells = data["S"]
+    rows = [S_cells[labels == l].sum(axis=0) if scale else S_cells[labels == l].mean(axis=0) for l in order]
+    S = np.stack(rows).astype(np.float32)
+    d_source = (counts[order] / counts.sum()).astype(np.float32)
+    G = data["G"]
+    d = (G.sum(1) / G.sum()).astype(np.float32) if prior == "rna_count_based" else (np.ones(V) / V).astype(np.float32)
+    return dict(S=S, G=G, d=d, d_source=d_source, S_cells=S_cells, labels=labels, order=order)
+
+
 def build_inputs(name):
     C, K, V, seed, epochs, mode, kw = CASES[name]
     kw = dict(kw)
+    if mode == "grid":
+        ci = cluster_inputs(C, K, V, seed, kw.pop("scale"), kw.pop("prior"))
+        args = dict(S=ci["S"], G=ci["G"], d=ci["d"], d_source=ci["d_source"])
+        args.update(kw)
+        return args, epochs, mode
     data = make_synthetic(C, K, V, seed=seed, n_types=5 if mode == "spatial" else 0)
     args = dict(S=data["S"], G=data["G"])
     if kw.pop("no_density", False):
@@ -137,7 +175,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     mo = load_ref()
-    for name in CASES:
+    names = sys.argv[1:] or list(CASES)          # optional: regenerate only the named cases
+    for name in names:
         o32 = run(mo, name, double=False)
         o64 = run(mo, name, double=True)
         blob = {}

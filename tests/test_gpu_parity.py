@@ -11,7 +11,7 @@ from oracle.gen_golden import CASES
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-MAPPER_CASES = [n for n, c in CASES.items() if c[5] in ("cells", "clusters", "constrained", "spatial", "autocorr")]
+MAPPER_CASES = [n for n, c in CASES.items() if c[5] in ("cells", "clusters", "constrained", "spatial", "autocorr", "grid")]
 
 
 def test_native_library_is_the_one_running():
