@@ -71,7 +71,7 @@ static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
     size_t o_Sk, o_St, o_StP, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
-        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X,
+        o_d, o_coef, o_vcoef, o_rshift, o_rinvz, o_rscale, o_rmul, o_fgate, o_densw, o_part, o_rowq, o_rowpair, o_scal, o_fsum, o_X,
         o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[6][3],
         o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
         o_accmpart, o_accm, o_actnorm, total;
@@ -166,6 +166,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_rshift = take((size_t)L->Cp * 4);
     L->o_rinvz = take((size_t)L->Cp * 4);
     L->o_rscale = take((size_t)L->Cp * 4);
+    L->o_rmul = take((size_t)L->Cp * 4);
     L->o_fgate = take((size_t)L->Cp * 4);
     L->o_densw = take((size_t)L->Cp * 4);
     const size_t np1 = L->full ? TGP1_N : 1;
@@ -309,7 +310,7 @@ static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize,
     a.part = parts; a.nparts = nparts; a.C = L.C;
     a.rshift = finalize ? m->fp(L.o_rshift) : nullptr;
     a.rinvz = m->fp(L.o_rinvz);
-    a.rscale = m->fp(L.o_rscale);
+    a.rmul = m->fp(L.o_rmul); a.rscale = m->fp(L.o_rscale);
     a.pair_out = want_pair ? m->fp(L.o_rowpair) : nullptr;
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
@@ -568,12 +569,14 @@ static void tg_band_range(const TgLayout& L, int b, int* ct0, int* ct1, int* c0,
 
 template <class PR>
 static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int band = -1,
-                             const unsigned char* St_alt = nullptr, const float* rlse2_alt = nullptr) {
+                             const unsigned char* St_alt = nullptr, bool unfiltered = false) {
     const TgLayout& L = m->L;
     if (band < 0) stream = m->stream;
     TgFwdArgs a;
     a.M = (const float*)(m->st + L.s_M);
-    a.rlse2 = rlse2_alt ? rlse2_alt : m->fp(L.o_rscale);
+    a.rmax = m->fp(L.o_rshift);
+    a.rmul = unfiltered ? (const float*)m->fp(L.o_rinvz) : (const float*)m->fp(L.o_rmul);     // f_c / Z_c (padding rows: 0)
+    a.rlse2 = unfiltered ? (const float*)m->fp(L.o_rowent) : (const float*)m->fp(L.o_rscale);
     a.St = St_alt ? St_alt : m->ws + L.o_St;
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
@@ -737,7 +740,7 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     u.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
     u.vcoef = m->fp(L.o_vcoef); u.r = m->fp(L.o_rowq);
     u.pair_out = m->fp(L.o_rowpair); u.rowq_out = m->fp(L.o_rowq);
-    u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_scale = m->fp(L.o_rscale);
+    u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_mul = m->fp(L.o_rmul); u.new_scale = m->fp(L.o_rscale);
     u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0; u.c_begin = c0;
     u.lambda_r = m->cfg.lambda_r; u.lambda_l1 = m->cfg.lambda_l1; u.lambda_l2 = m->cfg.lambda_l2;
     const double t = (double)(m->step + 1);
@@ -938,7 +941,7 @@ extern "C" int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev) {
 }
 
 template <class PR>
-static int tg_project_block(tg_mapper* m, const float* S_blk, long long ld_s, int kc, const float* rlse2_alt) {
+static int tg_project_block(tg_mapper* m, const float* S_blk, long long ld_s, int kc, bool unfiltered) {
     const TgLayout& L = m->L;
     TgPrepSArgs a;
     a.S = S_blk; a.C = L.C; a.K = kc; a.ldS = ld_s; a.aug = nullptr; a.ct = nullptr; a.T = 0;
@@ -946,7 +949,7 @@ static int tg_project_block(tg_mapper* m, const float* S_blk, long long ld_s, in
     a.St = m->ws + L.o_StP; a.Cp = L.Cp;
     const size_t n2 = (size_t)L.Kp * (L.Cp / PR::CH);
     TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
-    return tg_launch_forward<PR>(m, nullptr, -1, m->ws + L.o_StP, rlse2_alt);
+    return tg_launch_forward<PR>(m, nullptr, -1, m->ws + L.o_StP, unfiltered);
 }
 
 extern "C" int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t ld_s, int32_t n_genes, float* out_dev,
@@ -955,19 +958,18 @@ extern "C" int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t
     if (!S_dev || !out_dev) return tg_fail(TG_ERR_INVALID, "S or out is NULL");
     if (n_genes < 1 || ld_s < n_genes || ld_out < n_genes) return tg_fail(TG_ERR_INVALID, "n_genes < 1 or a row pitch smaller than n_genes");
     const TgLayout& L = m->L;
-    const float* rlse2_alt = nullptr;
-    if (unfiltered && m->cfg.mode == TG_MODE_CONSTRAINED) {     // adata_map.X is softmax(M) without the filter (mapping_optimizer.py:637)
+    // adata_map.X is softmax(M) without the filter (mapping_optimizer.py:637): row constants 1/Z and (max + ln Z) log2(e)
+    const bool plain = unfiltered && m->cfg.mode == TG_MODE_CONSTRAINED;
+    if (plain)
         TG_LAUNCH(tg_plain_rscale, (L.C + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_rshift),
                   (const float*)m->fp(L.o_rinvz), L.C, m->fp(L.o_rowent));
-        rlse2_alt = m->fp(L.o_rowent);
-    }
     for (int k0 = 0; k0 < n_genes; k0 += L.K) {
         const int kc = (n_genes - k0 < L.K) ? n_genes - k0 : L.K;
         int rc;
         switch (m->cfg.precision) {
-            case TG_PREC_F32: rc = tg_project_block<PrecF32>(m, S_dev + k0, ld_s, kc, rlse2_alt); break;
-            case TG_PREC_BF16: rc = tg_project_block<PrecBF16>(m, S_dev + k0, ld_s, kc, rlse2_alt); break;
-            default: rc = tg_project_block<PrecBF16x3>(m, S_dev + k0, ld_s, kc, rlse2_alt); break;
+            case TG_PREC_F32: rc = tg_project_block<PrecF32>(m, S_dev + k0, ld_s, kc, plain); break;
+            case TG_PREC_BF16: rc = tg_project_block<PrecBF16>(m, S_dev + k0, ld_s, kc, plain); break;
+            default: rc = tg_project_block<PrecBF16x3>(m, S_dev + k0, ld_s, kc, plain); break;
         }
         if (rc) return rc;
         if ((rc = tg_launch_ghat_stats(m))) return rc;

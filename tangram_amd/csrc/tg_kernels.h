@@ -178,8 +178,12 @@ TG_HD bool tg_tilemap(const TgTileMap& m, int b, int& major, int& minor) {
 // ----------------------------------------------------------------------------------------------
 struct TgFwdArgs {
     const float* M;
-    const float* rlse2;      // [Cp] per-row log2-domain log-sum-exp: (max + ln Z - ln f_c) * log2(e), so that
-                             //      P_cv f_c = exp2(M_cv * log2(e) - rlse2_c) is ONE fma + ONE v_exp_f32; padding = +3e38 (=> 0)
+    const float* rmax;       // [Cp] per-row max of M (softmax shift); padding = +3e38 (=> P = 0)
+    const float* rmul;       // [Cp] per-row factor f_c / Z_c: P_cv f_c = exp2((M_cv - max_c) * log2(e)) * rmul_c   (fp32, bf16x3)
+    const float* rlse2;      // [Cp] (max + ln Z - ln f_c) * log2(e): P_cv f_c = exp2(M_cv * log2(e) - rlse2_c), ONE fma + ONE v_exp_f32.
+                             //      Only the bf16 path uses this folded form: the argument is ~20 even for the dominant entries and
+                             //      its fp32 rounding costs ~7e-7 relative in every P -- invisible next to bf16 operands (2^-9), but
+                             //      10x the reference's softmax error on the fp32-parity paths.
     const unsigned char* St; // [Kp][nsteps][128 B]
     float* Gpart;            // [nsplit][Vr][Kp]
     int C, V, Vp, Vr, Kp, Cp;
@@ -237,7 +241,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     const bool full_tile = (v0 + GE::TM) <= a.V;               // wave-uniform: interior tiles skip the per-element selects
 
     f32x4 mreg[RS];
-    float sh[RS];
+    float sh[RS], mu[RS];
     TgKTile<GE::TN, GE::NT> breg;
     const size_t bpitch = (size_t)a.nsteps * 128;
 
@@ -249,7 +253,10 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     auto load_sh = [&](int step) {
         const int cb = step * PR::BKE + kc * PR::CH + half * RS;
 #pragma unroll
-        for (int j = 0; j < RS; ++j) sh[j] = a.rlse2[cb + j];
+        for (int j = 0; j < RS; ++j) {
+            if constexpr (PR::kId == 1) { sh[j] = a.rlse2[cb + j]; mu[j] = 1.f; }
+            else { sh[j] = a.rmax[cb + j]; mu[j] = a.rmul[cb + j]; }
+        }
     };
     auto load_stage = [&](int step) {
 #pragma unroll
@@ -277,7 +284,8 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             float x[RS];
 #pragma unroll
             for (int j = 0; j < RS; ++j) {
-                const float p = tg_exp2(fmaf(mreg[j][i], TG_LOG2E, -sh[j]));
+                const float p = (PR::kId == 1) ? tg_exp2(fmaf(mreg[j][i], TG_LOG2E, -sh[j]))
+                                               : tg_exp2((mreg[j][i] - sh[j]) * TG_LOG2E) * mu[j];
                 x[j] = (full_tile || vok[i]) ? p : 0.f;
             }
             const int row = 4 * quad + i;
@@ -1175,7 +1183,8 @@ struct TgUpdateArgs {
     const float* r;                                   // [C] row dots
     float* pair_out;                                  // [2][C] (max, Z) of the new row (cross-GPU exchange)
     float* rowq_out;                                  // [TGP1_N][C] row sums written by tg_adam_rowpass (FULL), else unused
-    float* new_shift; float* new_invz; float* new_scale;   // finalised statistics (single GPU) or null
+    float* new_shift; float* new_invz; float* new_mul; float* new_scale;   // finalised statistics (single GPU) or null; new_mul = 1/Z and
+                                                                           // new_scale = (max + ln Z) log2(e) are the forward's row constants
     int C, V, Vp, Vr, finalize;
     int c_begin;                                      // first cell of this launch (grid = number of cells)
     float lambda_r, lambda_l1, lambda_l2;
@@ -1255,7 +1264,8 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
             const float inz = 1.f / z;
             a.new_shift[c] = mx;
             a.new_invz[c] = inz;
-            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;      // (the constrained filter is folded in by tg_merge_stats)
+            a.new_mul[c] = 1.f / z;                            // (the constrained filter is folded in by tg_merge_stats)
+            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
         }
     }
 }
@@ -1407,6 +1417,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(
         if (a.finalize) {
             a.new_shift[c] = mx;
             a.new_invz[c] = 1.f / z;
+            a.new_mul[c] = 1.f / z;
             a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
         }
     }
@@ -1522,7 +1533,7 @@ struct TgMergeArgs {
     int nparts, C;
     float* rshift; float* rinvz;       // final (may be null when only the local pair is wanted)
     float* pair_out;           // [2][C] local (max, Z) for the cross-GPU exchange, or null
-    const float* fgate; float* rscale; // forward log2-domain lse: (max + ln Z - ln f_c) * log2(e)
+    const float* fgate; float* rmul; float* rscale;   // forward row constants: f_c / Z_c and (max + ln Z - ln f_c) * log2(e)
 };
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -1537,11 +1548,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
         const float iz = 1.f / z;
         a.rshift[c] = mx;
         a.rinvz[c] = iz;
-        a.rscale[c] = (mx + tg_log(z) - (a.fgate ? tg_log(a.fgate[c]) : 0.f)) * TG_LOG2E;   // log2-domain lse for the forward
+        a.rmul[c] = (a.fgate ? a.fgate[c] : 1.f) * iz;
+        a.rscale[c] = (mx + tg_log(z) - (a.fgate ? tg_log(a.fgate[c]) : 0.f)) * TG_LOG2E;
     }
 }
 
-// forward row scale WITHOUT the constrained-mode filter: (max + ln Z) * log2(e)
+// forward row constant of the bf16 path WITHOUT the constrained-mode filter: (max + ln Z) * log2(e)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_plain_rscale(const float* rshift, const float* rinvz, int C, float* out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) out[c] = (rshift[c] - tg_log(rinvz[c])) * TG_LOG2E;

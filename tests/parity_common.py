@@ -68,7 +68,8 @@ def check_against_golden(res, precision, full_length):
         over = np.nonzero(own > tol["loss"] * scale / 3.0)[0]
         well = int(over[0]) if len(over) else n
         if res["mode"] == "grid":
-            well = min(well, 100)        # round-off grows ~10x per 50 epochs on these cases; any two fp32 implementations part ways by ~150
+            well = min(well, 100 if precision != "bf16" else 50)   # round-off grows ~10x per 50 epochs on these cases; any two fp32
+                                                                  # implementations part ways by ~150 (bf16 operands: earlier)
         assert well >= min(n, 50), f"{k}: fixture ill-conditioned from epoch {well}"
         err = float(np.abs(got[:well] - ref[:well]).max())
         assert err <= tol["loss"] * scale, f"{k}: max per-epoch |delta| {err:.3e} > {tol['loss'] * scale:.1e}"
