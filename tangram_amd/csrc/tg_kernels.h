@@ -278,31 +278,48 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             else tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)step, st + GE::A_CHUNKS, t, wave, k - RS - 1, GE::LB);
         }
     };
-    auto store_stage = [&](u32x4* st) {
+    // (MASKED: edge tiles zero the spots >= V; interior tiles skip the 16 selects.  bf16x3: the arithmetic runs on pairs of
+    //  cells so that the compiler can use the packed-fp32 VALU ops, v_pk_add_f32 / v_pk_mul_f32: the staging is VALU-bound.)
+    auto store_stage_impl = [&](u32x4* st, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float x[RS];
-#pragma unroll
-            for (int j = 0; j < RS; ++j) {
-                const float p = (PR::kId == 1) ? tg_exp2(fmaf(mreg[j][i], TG_LOG2E, -sh[j]))
-                                               : tg_exp2((mreg[j][i] - sh[j]) * TG_LOG2E) * mu[j];
-                x[j] = (full_tile || vok[i]) ? p : 0.f;
-            }
             const int row = 4 * quad + i;
             if constexpr (PR::NP == 2) {
-                const unsigned h0 = tg_pack_bf16(x[0], x[1]), h1 = tg_pack_bf16(x[2], x[3]);
-                const unsigned l0 = tg_pack_bf16(x[0] - tg_bf16_lo_to_f32(h0), x[1] - tg_bf16_hi_to_f32(h0));
-                const unsigned l1 = tg_pack_bf16(x[2] - tg_bf16_lo_to_f32(h1), x[3] - tg_bf16_hi_to_f32(h1));
+                unsigned h[2], l[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x2 m2 = {mreg[2 * q][i], mreg[2 * q + 1][i]};
+                    const f32x2 sh2 = {sh[2 * q], sh[2 * q + 1]}, mu2 = {mu[2 * q], mu[2 * q + 1]};
+                    const f32x2 tt = (m2 - sh2) * TG_LOG2E;
+                    f32x2 x2 = f32x2{tg_exp2(tt[0]), tg_exp2(tt[1])} * mu2;
+                    if (MASKED && !vok[i]) x2 = f32x2{0.f, 0.f};
+                    h[q] = tg_pack_bf16(x2[0], x2[1]);
+                    const f32x2 hf = {tg_bf16_lo_to_f32(h[q]), tg_bf16_hi_to_f32(h[q])};
+                    const f32x2 l2 = x2 - hf;
+                    l[q] = tg_pack_bf16(l2[0], l2[1]);
+                }
                 u32x2* hp = (u32x2*)(st + row * 8 + tg_swz(row, kc));
                 u32x2* lp = (u32x2*)(st + row * 8 + tg_swz(row, 4 + kc));
-                hp[half] = u32x2{h0, h1};
-                lp[half] = u32x2{l0, l1};
+                hp[half] = u32x2{h[0], h[1]};
+                lp[half] = u32x2{l[0], l[1]};
             } else {
+                float x[RS];
+#pragma unroll
+                for (int j = 0; j < RS; ++j) {
+                    const float p = (PR::kId == 1) ? tg_exp2(fmaf(mreg[j][i], TG_LOG2E, -sh[j]))
+                                                   : tg_exp2((mreg[j][i] - sh[j]) * TG_LOG2E) * mu[j];
+                    x[j] = (full_tile || vok[i]) ? p : 0.f;
+                }
                 u32x4 hi, lo;
                 PR::cvt(x, hi, lo);
                 st[row * 8 + tg_swz(row, slot)] = hi;
             }
         }
+    };
+    auto store_stage = [&](u32x4* st) {
+        if (PR::NP == 2 && full_tile) store_stage_impl(st, std::false_type());     // (the second copy only pays off for bf16x3)
+        else store_stage_impl(st, std::true_type());
         if (!TG_GLDS) breg.store(st + GE::A_CHUNKS, t);
     };
 
