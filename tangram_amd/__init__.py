@@ -4,5 +4,6 @@ behind a C ABI (include/tangram_hip.h).  Importing this package does not import 
 from .mapping_optimizer import Mapper, MapperConstrained          # noqa: F401
 from .mapping_utils import map_cells_to_space, adata_to_cluster_expression  # noqa: F401
 from .utils import project_genes                                  # noqa: F401
+from .batched import train_many                                   # noqa: F401
 
 __version__ = "0.1.0"

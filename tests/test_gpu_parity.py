@@ -273,3 +273,33 @@ def test_update_kernel_row_lengths(V, variant):
         np.testing.assert_allclose(F.cpu().numpy(), res[1], atol=2e-5)
     else:
         np.testing.assert_allclose(e.result().cpu().numpy(), res[0], atol=2e-5)
+
+
+def test_concurrent_mappings_bit_identical():
+    """tangram_amd.train_many: independent mappings on separate HIP streams and host threads must give the very
+    bits of the same mappings trained one after the other (handles share nothing), for Mapper and MapperConstrained."""
+    import tangram_amd as tg
+    import tangram_amd.mapping_optimizer as mo
+    from oracle import tangram_oracle as orc
+    data = orc.make_synthetic(24, 40, 300, seed=4)
+    ds = np.full(24, 1.0 / 24, np.float32)
+
+    def cells(i):
+        keep = [g for g in range(40) if g != i]
+        return lambda: mo.Mapper(S=data["S"][:, keep], G=data["G"][:, keep], d=data["d"], d_source=ds, lambda_d=1, lambda_g2=0.5,
+                                 device=DEV, random_state=i + 1)
+
+    def constrained(i):
+        return lambda: mo.MapperConstrained(S=data["S"], G=data["G"], d=data["d"], lambda_d=1, lambda_count=1, lambda_f_reg=1,
+                                            target_count=100, device=DEV, random_state=i + 1)
+
+    builders = [cells(i) for i in range(5)] + [constrained(i) for i in range(3)]
+    seq = [b().train(num_epochs=120, learning_rate=0.1, print_each=None) for b in builders]
+    res, mappers = tg.train_many(builders, 120, 0.1, max_concurrent=4, device=DEV)
+    assert len(res) == len(seq) == len(mappers)
+    for a, b in zip(seq, res):
+        assert len(a) == len(b)
+        np.testing.assert_array_equal(a[0], b[0])
+        if len(a) == 3:
+            np.testing.assert_array_equal(a[1], b[1])
+        assert list(a[-1]["main_loss"]) == list(b[-1]["main_loss"])
