@@ -37,8 +37,13 @@ def main():
         t_enq = time.perf_counter() - t0
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
+        e.eng.profile(True)
+        e.run(20, 0.1)
+        torch.cuda.synchronize()
+        kern = {name: round(1e3 * ms / max(cnt, 1), 1) for name, ms, cnt in e.eng.profile_read()}
+        e.eng.profile(False)
         out[f"{C}x{K}x{Vl}_of_{parts}_{prec}"] = dict(ms_per_step=1e3 * t_all / n, host_enqueue_ms_per_step=1e3 * t_enq / n,
-                                                      main_loss=float(hist[-1, 1]))
+                                                      main_loss=float(hist[-1, 1]), kernels_us=kern)
         del e, w, M0
     print(json.dumps(out))
     dist.destroy_process_group()

@@ -239,6 +239,9 @@ struct tg_mapper {
     bool ready;
     tg_stream_t s_adam, s_fwd;                       // library-owned streams of the cell-band pipeline
     tg_event_t e_bwd[TG_MAX_BANDS], e_adam[TG_MAX_BANDS], e_fwd;
+    // history scalars deferred from tg_launch_loss to one extra workgroup of the next update kernel (tg_dghat_emit<SELF>)
+    bool fin_pending;
+    TgFinalizeArgs fin_args;
     // profiling
     bool prof;
     std::vector<std::string> prof_names;
@@ -498,7 +501,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     m->cfg = *cfg; m->L = L;
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
-    m->step = 0; m->ready = false; m->prof = false;
+    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false;
     m->s_adam = nullptr; m->s_fwd = nullptr;
     if (L.bands > 1) {
         int e = tg_stream_create(&m->s_adam) | tg_stream_create(&m->s_fwd) | tg_event_create(&m->e_fwd);
@@ -629,19 +632,31 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     f.nbcoef = L.has_nb ? m->fp(L.o_nbcoef) : nullptr;
     f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.V;
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
+    TgEmitArgs e;
+    e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
+    e.dG = m->ws + L.o_dG;
+    e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) : nullptr;
+    e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
+    e.fin = f;
+    // Without spatial terms every gradient coefficient is a local function of the reduced statistics: the emit kernel
+    // derives them itself and the scalars of the history row are left to one extra workgroup of the update kernel.
+    // (single GPU only: on a spot shard tg_hist_regs has to see the base row before the row sums are all-reduced)
+    const bool self = !e.extra && L.bands == 1 && L.Vtot == L.V && (size_t)(2 * L.Kp + 2 * TG_RB) * 4 <= 48 * 1024;
+    if (self) {
+        m->fin_args = f; m->fin_pending = true;
+        TG_LAUNCH((tg_dghat_emit<PR, false, true>), (L.V + TG_RB - 1) / TG_RB, 1, 256, (2 * L.Kp + 2 * TG_RB) * 4, m->stream, e);
+        tg_prof_mark(m, "tg_dghat_emit");
+        return TG_OK;
+    }
+    m->fin_pending = false;
     int rcs = tg_launch_spatial_stats(m);
     if (rcs) return rcs;
     TG_LAUNCH(tg_loss_finalize, 1, 1, 1024, 16 * 5 * 4, m->stream, f);
     tg_prof_mark(m, "tg_loss_finalize");
     if ((rcs = tg_launch_spatial_grad(m))) return rcs;
     if (L.has_ac && (rcs = tg_launch_autocorr(m, hist_row))) return rcs;
-    TgEmitArgs e;
-    e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
-    e.dG = m->ws + L.o_dG;
-    e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) : nullptr;
-    e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
-    if (e.extra) TG_LAUNCH((tg_dghat_emit<PR, true>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
-    else TG_LAUNCH((tg_dghat_emit<PR, false>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
+    if (e.extra) TG_LAUNCH((tg_dghat_emit<PR, true, false>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
+    else TG_LAUNCH((tg_dghat_emit<PR, false, false>), (L.V + TG_RB - 1) / TG_RB, 1, 256, 0, m->stream, e);
     tg_prof_mark(m, "tg_dghat_emit");
     return TG_OK;
 }
@@ -704,7 +719,7 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     tg_prof_mark(m, "tg_bwd_kernel");
     tg_launch_rowsum(m, m->stream, 0, L.C);
     tg_prof_mark(m, "tg_rowsum_parts");
-    if (L.full) {
+    if (L.full && !m->fin_pending) {          // (deferred history row: tg_one_step launches this after the update kernel)
         tg_launch_hist_regs(m, m->stream, hist_row);
         tg_prof_mark(m, "tg_hist_regs");
     }
@@ -748,14 +763,17 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
     u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
     const bool x16 = (m->cfg.precision == TG_PREC_BF16);     // PrecBF16::X16
+    u.fin_on = 0;
+    int extra_wg = 0;
+    if (m->fin_pending && whole) { u.fin = m->fin_args; u.fin_on = 1; extra_wg = 1; m->fin_pending = false; }
     if (rowpass) {
-        if (L.full) { if (x16) tg_launch_rowpass<true, true>(u, c1 - c0, L.V, stream); else tg_launch_rowpass<true, false>(u, c1 - c0, L.V, stream); }
-        else { if (x16) tg_launch_rowpass<false, true>(u, c1 - c0, L.V, stream); else tg_launch_rowpass<false, false>(u, c1 - c0, L.V, stream); }
+        if (L.full) { if (x16) tg_launch_rowpass<true, true>(u, c1 - c0 + extra_wg, L.V, stream); else tg_launch_rowpass<true, false>(u, c1 - c0 + extra_wg, L.V, stream); }
+        else { if (x16) tg_launch_rowpass<false, true>(u, c1 - c0 + extra_wg, L.V, stream); else tg_launch_rowpass<false, false>(u, c1 - c0 + extra_wg, L.V, stream); }
         if (whole) tg_prof_mark(m, "tg_adam_rowpass");
         return TG_OK;
     }
-    if (L.full) { if (x16) TG_LAUNCH((tg_adam_update<true, true>), c1 - c0, 1, 256, 64, stream, u); else TG_LAUNCH((tg_adam_update<true, false>), c1 - c0, 1, 256, 64, stream, u); }
-    else { if (x16) TG_LAUNCH((tg_adam_update<false, true>), c1 - c0, 1, 256, 64, stream, u); else TG_LAUNCH((tg_adam_update<false, false>), c1 - c0, 1, 256, 64, stream, u); }
+    if (L.full) { if (x16) TG_LAUNCH((tg_adam_update<true, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); else TG_LAUNCH((tg_adam_update<true, false>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); }
+    else { if (x16) TG_LAUNCH((tg_adam_update<false, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); else TG_LAUNCH((tg_adam_update<false, false>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); }
     if (whole) tg_prof_mark(m, "tg_adam_update");
     return TG_OK;
 }
@@ -778,8 +796,13 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
             tg_prof_mark(m, "tg_hist_regs");
         }
     } else {
+        const bool deferred = m->fin_pending;
         if ((rc = tg_launch_rowdots<PR>(m, hist_row))) return rc;
         if ((rc = tg_launch_update(m, lr, !constrained))) return rc;
+        if (m->L.full && deferred) {
+            tg_launch_hist_regs(m, m->stream, hist_row);
+            tg_prof_mark(m, "tg_hist_regs");
+        }
     }
     if (constrained) {      // Adam on F, then fold the NEW filter into the forward row scale
         if ((rc = tg_launch_filter(m, true, lr, hist_row))) return rc;

@@ -508,9 +508,47 @@ TG_DEV float tg_block_sum_1024(float x, float* red) {
     for (int w = 0; w < nw; ++w) s += red[w];
     return s;
 }
-// N block sums with ONE pair of barriers (same fixed summation order as N calls of tg_block_sum_1024)
+// per-gene gradient coefficients and cosine term: dGhat_vk (gene term) = al G_vk + be Ghat_vk
+TG_DEV void tg_gene_coef(const TgFinalizeArgs& a, const float* stat, const float* gn2, float lambda, int k, float& al, float& be, float& c) {
+    const float dot = stat[k];
+    const float na = tg_fmax(sqrtf(stat[a.Kp + k]), TG_COS_EPS);
+    const float nb = tg_fmax(sqrtf(gn2[k]), TG_COS_EPS);
+    c = dot / (na * nb);
+    const float w = lambda / (float)a.K;
+    al = -w / (na * nb);
+    be = w * c / (na * na);
+}
+// per-spot coefficients from loaded statistics: voxel cosine term (va, vb, cosine c) and density term (a_v, KL summand)
+TG_DEV void tg_spot_coef(const TgFinalizeArgs& a, float dot, float n2a, float n2b, float colsum, float dv, float rho_scale,
+                         float& va, float& vb, float& av, float& c, float& kl) {
+    va = vb = av = c = kl = 0.f;
+    if (a.lambda_g2 != 0.f) {
+        const float na = tg_fmax(sqrtf(n2a), TG_COS_EPS);
+        const float nb = tg_fmax(sqrtf(n2b), TG_COS_EPS);
+        c = dot / (na * nb);
+        const float w = a.lambda_g2 / (float)a.V_total;
+        va = -w / (na * nb);
+        vb = w * c / (na * na);
+    }
+    if (a.has_density) {
+        const float rho = colsum * rho_scale;
+        if (dv != 0.f) kl = dv * (tg_log(dv) - tg_log(rho));   // KLDivLoss(sum): xlogy(d,d) - d*log(rho)
+        av = -a.lambda_d * dv * rho_scale / rho;                // = -lambda_d d_v / colsum_v
+    }
+}
+TG_DEV void tg_spot_stats_load(const TgFinalizeArgs& a, int v, float& dot, float& n2a, float& n2b, float& colsum, float& dv) {
+    const bool in = v < a.V;
+    dot = 0.f; n2a = (in && a.lambda_g2 != 0.f) ? 0.f : 1.f;
+    if (in && a.lambda_g2 != 0.f)
+        for (int y = 0; y < a.nky; ++y) { dot += a.voxstat[((size_t)y * 2 + 0) * a.Vr + v]; n2a += a.voxstat[((size_t)y * 2 + 1) * a.Vr + v]; }
+    n2b = (in && a.lambda_g2 != 0.f) ? a.vnorm2[v] : 1.f;
+    colsum = (in && a.has_density) ? a.Ghat[(size_t)v * a.Kp + a.K] : 1.f;
+    dv = (in && a.has_density) ? a.d[v] : 0.f;
+}
+
+// N block sums with ONE pair of barriers, any block size that is a multiple of 64 (fixed summation order)
 template <int N>
-TG_DEV void tg_block_sums_1024(float (&x)[N], float* red) {
+TG_DEV void tg_block_sums(float (&x)[N], float* red) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -530,90 +568,49 @@ TG_DEV void tg_block_sums_1024(float (&x)[N], float* red) {
     }
 }
 
-TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
-    TG_LDS_DECL;
-    float* red = (float*)tg_lds;
-    const int t = threadIdx.x;
+// The scalars of one iteration -> history row; with WRITE also the gradient coefficient vectors (coef, nbcoef, vcoef).
+// One workgroup of any size (multiple of 64); `red` needs (blockDim / 64) * 5 floats.
+template <bool WRITE>
+TG_DEV void tg_loss_scalars(const TgFinalizeArgs& a, float* red) {
+    const int t = threadIdx.x, nt = blockDim.x;
     float cs = 0.f;
-    for (int k = t; k < a.Kp; k += 1024) {
-        float al = 0.f, be = 0.f;
-        if (k < a.K) {
-            const float dot = a.genestat[k];
-            const float na = tg_fmax(sqrtf(a.genestat[a.Kp + k]), TG_COS_EPS);
-            const float nb = tg_fmax(sqrtf(a.gnorm2[k]), TG_COS_EPS);
-            const float c = dot / (na * nb);
-            cs += c;
-            const float w = a.lambda_g1 / (float)a.K;
-            al = -w / (na * nb);
-            be = w * c / (na * na);
-        }
-        a.coef[k] = al;
-        a.coef[a.Kp + k] = be;
+    for (int k = t; k < a.Kp; k += nt) {
+        float al = 0.f, be = 0.f, c = 0.f;
+        if (k < a.K) { tg_gene_coef(a, a.genestat, a.gnorm2, a.lambda_g1, k, al, be, c); cs += c; }
+        if (WRITE) { a.coef[k] = al; a.coef[a.Kp + k] = be; }
     }
     float nbs = 0.f;
     if (a.nbstat) {
-        for (int k = t; k < a.Kp; k += 1024) {
-            float al = 0.f, be = 0.f;
-            if (k < a.K) {
-                const float dot = a.nbstat[k];
-                const float na = tg_fmax(sqrtf(a.nbstat[a.Kp + k]), TG_COS_EPS);
-                const float nb = tg_fmax(sqrtf(a.wgnorm2[k]), TG_COS_EPS);
-                const float c = dot / (na * nb);
-                nbs += c;
-                const float w = a.lambda_nb / (float)a.K;
-                al = -w / (na * nb);
-                be = w * c / (na * na);
-            }
-            a.nbcoef[k] = al;
-            a.nbcoef[a.Kp + k] = be;
+        for (int k = t; k < a.Kp; k += nt) {
+            float al = 0.f, be = 0.f, c = 0.f;
+            if (k < a.K) { tg_gene_coef(a, a.nbstat, a.wgnorm2, a.lambda_nb, k, al, be, c); nbs += c; }
+            if (WRITE) { a.nbcoef[k] = al; a.nbcoef[a.Kp + k] = be; }
         }
     }
     float cts = 0.f;
-    if (a.ctpart) for (int i = t; i < a.n_ctpart; i += 1024) cts += a.ctpart[i];
+    if (a.ctpart) for (int i = t; i < a.n_ctpart; i += nt) cts += a.ctpart[i];
+
     float vs = 0.f, kl = 0.f;
     const float rho_scale = a.fsum_dev ? 1.f / a.fsum_dev[0] : a.rho_scale;
     // (4 spots per trip with all their loads issued first: this single-workgroup loop is pure memory latency)
-    for (int vb0 = t; vb0 < a.Vr; vb0 += 4 * 1024) {
+    for (int vb0 = t; vb0 < a.Vr; vb0 += 4 * nt) {
         float dot[4], n2a[4], n2b[4], colsum[4], dv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int v = vb0 + u * 1024;
-            const bool in = v < a.V;
-            dot[u] = 0.f; n2a[u] = (in && a.lambda_g2 != 0.f) ? 0.f : 1.f;
-            if (in && a.lambda_g2 != 0.f)
-                for (int y = 0; y < a.nky; ++y) { dot[u] += a.voxstat[((size_t)y * 2 + 0) * a.Vr + v]; n2a[u] += a.voxstat[((size_t)y * 2 + 1) * a.Vr + v]; }
-            n2b[u] = (in && a.lambda_g2 != 0.f) ? a.vnorm2[v] : 1.f;
-            colsum[u] = (in && a.has_density) ? a.Ghat[(size_t)v * a.Kp + a.K] : 1.f;
-            dv[u] = (in && a.has_density) ? a.d[v] : 0.f;
-        }
+        for (int u = 0; u < 4; ++u) tg_spot_stats_load(a, vb0 + u * nt, dot[u], n2a[u], n2b[u], colsum[u], dv[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int v = vb0 + u * 1024;
+            const int v = vb0 + u * nt;
             if (v >= a.Vr) continue;
-            float va = 0.f, vb = 0.f, av = 0.f;
+            float va = 0.f, vb = 0.f, av = 0.f, c = 0.f, klv = 0.f;
             if (v < a.V) {
-                if (a.lambda_g2 != 0.f) {
-                    const float na = tg_fmax(sqrtf(n2a[u]), TG_COS_EPS);
-                    const float nb = tg_fmax(sqrtf(n2b[u]), TG_COS_EPS);
-                    const float c = dot[u] / (na * nb);
-                    vs += c;
-                    const float w = a.lambda_g2 / (float)a.V_total;
-                    va = -w / (na * nb);
-                    vb = w * c / (na * na);
-                }
-                if (a.has_density) {
-                    const float rho = colsum[u] * rho_scale;
-                    if (dv[u] != 0.f) kl += dv[u] * (tg_log(dv[u]) - tg_log(rho));   // KLDivLoss(sum): xlogy(d,d) - d*log(rho)
-                    av = -a.lambda_d * dv[u] * rho_scale / rho;                      // = -lambda_d d_v / colsum_v
-                }
+                tg_spot_coef(a, dot[u], n2a[u], n2b[u], colsum[u], dv[u], rho_scale, va, vb, av, c, klv);
+                vs += c; kl += klv;
             }
-            a.vcoef[v] = va;
-            a.vcoef[a.Vr + v] = vb;
-            a.vcoef[2 * a.Vr + v] = av;
+            if (WRITE) { a.vcoef[v] = va; a.vcoef[a.Vr + v] = vb; a.vcoef[2 * a.Vr + v] = av; }
         }
     }
     float sums[5] = {cs, nbs, cts, vs, kl};           // the five scalars share one block reduction
-    tg_block_sums_1024(sums, red);
+    tg_block_sums(sums, red);
     const float gv = sums[0] / (float)a.K, nbv = sums[1] / (float)a.K;
     const float isl = sums[2] / ((float)a.V * (float)(a.T > 0 ? a.T : 1));
     const float vg = sums[3] / (float)a.V_total, klsum = sums[4];
@@ -632,6 +629,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
     }
 }
 
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_loss_finalize(TgFinalizeArgs a) {
+    TG_LDS_DECL;
+    tg_loss_scalars<true>(a, (float*)tg_lds);
+}
+
 // ----------------------------------------------------------------------------------------------
 // K2d: dGhat in operand format (contraction axis = genes), rows = spots: [Vr][Kp/BKE steps][128 B]
 // ----------------------------------------------------------------------------------------------
@@ -640,26 +642,55 @@ struct TgEmitArgs {
     const float* extra;        // [Vr][Kp] additional d(loss)/dGhat (spatial terms; also feeds the augmentation columns) or null
     unsigned char* dG;
     int V, Vr, Kp, K, n_aug;   // columns K+1 .. K+n_aug-1 carry the cell-type gradient
+    TgFinalizeArgs fin;        // SELF: the statistics the coefficients are derived from (coef / vcoef above are then unused)
 };
 
-template <class PR, bool EXTRA>
+// SELF: the workgroup derives the per-gene (alpha, beta) and its 16 per-spot (va, vb, a_v) coefficients itself, from the
+// reduced statistics, into LDS -- they are purely local functions of them.  tg_loss_finalize (one workgroup, ~20 us of
+// dependent latency) then no longer sits between the forward and the backward GEMM: the scalars of the history row are
+// produced by one extra workgroup of the update kernel, off the critical path.  dynamic LDS: (2 Kp + 2 TG_RB) floats.
+template <class PR, bool EXTRA, bool SELF>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
+    TG_LDS_DECL;
+    float* cf = (float*)tg_lds;                          // SELF: [2][Kp] alpha, beta; then [2][TG_RB] va, vb
     constexpr int NQ = PR::CH / 4;                       // float4 groups per operand chunk
     const int nch = a.Kp / PR::CH;
     const int vbeg = blockIdx.x * TG_RB;
     const size_t pitch = (size_t)(a.Kp / PR::BKE) * 128;
+    const float* coef = a.coef;
+    if constexpr (SELF) {
+        for (int k = threadIdx.x; k < a.Kp; k += 256) {
+            float al = 0.f, be = 0.f, c = 0.f;
+            if (k < a.K) tg_gene_coef(a.fin, a.fin.genestat, a.fin.gnorm2, a.fin.lambda_g1, k, al, be, c);
+            cf[k] = al; cf[a.Kp + k] = be;
+        }
+        if (threadIdx.x < TG_RB) {
+            const int v = vbeg + threadIdx.x;
+            float va = 0.f, vb = 0.f, av = 0.f, c = 0.f, kl = 0.f;
+            if (v < a.V) {
+                float dot, n2a, n2b, colsum, dv;
+                tg_spot_stats_load(a.fin, v, dot, n2a, n2b, colsum, dv);
+                const float rho_scale = a.fin.fsum_dev ? 1.f / a.fin.fsum_dev[0] : a.fin.rho_scale;
+                tg_spot_coef(a.fin, dot, n2a, n2b, colsum, dv, rho_scale, va, vb, av, c, kl);
+            }
+            cf[2 * a.Kp + threadIdx.x] = va; cf[2 * a.Kp + TG_RB + threadIdx.x] = vb;
+            if (v < a.Vr) { a.fin.vcoef[v] = va; a.fin.vcoef[a.Vr + v] = vb; a.fin.vcoef[2 * a.Vr + v] = av; }   // a_v: read by the backward / update kernels
+        }
+        __syncthreads();
+        coef = cf;
+    }
     for (int idx = threadIdx.x; idx < nch * TG_RB; idx += 256) {
         const int i = idx / nch, ch = idx % nch;
         const int v = vbeg + i;
         if (v >= a.V) continue;
         const int k = ch * PR::CH;
-        const float va = a.vcoef[v], vb = a.vcoef[a.Vr + v];
+        const float va = SELF ? cf[2 * a.Kp + i] : a.vcoef[v], vb = SELF ? cf[2 * a.Kp + TG_RB + i] : a.vcoef[a.Vr + v];
         float x[PR::CH];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const size_t off = (size_t)v * a.Kp + k + 4 * q;
             const f32x4 gh = *(const f32x4*)(a.Ghat + off), g = *(const f32x4*)(a.G + off);
-            const f32x4 ca = *(const f32x4*)(a.coef + k + 4 * q), cb = *(const f32x4*)(a.coef + a.Kp + k + 4 * q);
+            const f32x4 ca = *(const f32x4*)(coef + k + 4 * q), cb = *(const f32x4*)(coef + a.Kp + k + 4 * q);
             f32x4 ex = {0.f, 0.f, 0.f, 0.f};
             if (EXTRA) ex = *(const f32x4*)(a.extra + off);
 #pragma unroll
@@ -1206,12 +1237,15 @@ struct TgUpdateArgs {
     int c_begin;                                      // first cell of this launch (grid = number of cells)
     float lambda_r, lambda_l1, lambda_l2;
     float step_size, bc2_sqrt, beta1, beta2, eps;
+    int fin_on;                                       // 1: the LAST workgroup of the grid computes the history scalars instead of a row
+    TgFinalizeArgs fin;                               //    (tg_loss_scalars; see tg_dghat_emit<SELF>)
 };
 
 template <bool FULL, bool X16>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     TG_LDS_DECL;
-    float* red = (float*)tg_lds;          // [4 waves][2]
+    float* red = (float*)tg_lds;          // [4 waves][2]  (history workgroup: [4][5])
+    if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
     const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float sh = a.rshift[c], iz = a.rinvz[c], rc = a.r[c];
     const float fg = a.fgate ? a.fgate[c] : 1.f;
@@ -1298,6 +1332,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [NW waves][TGP1_N] then [NW][2]
     constexpr int NW = NT / 64;
+    if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
     constexpr int NP = FULL ? (int)TGP1_N : 1;
     const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float sh = a.rshift[c], iz = a.rinvz[c];
