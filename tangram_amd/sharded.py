@@ -19,6 +19,24 @@ from . import _capi
 from .engine import HipMapperEngine
 
 
+class DistComm:
+    """The collectives of the sharded step on a torch.distributed process group (RCCL on GPUs)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce(self, t):
+        dist.all_reduce(t, group=self.group)
+
+    def all_gather_into_tensor(self, out, t):
+        dist.all_gather_into_tensor(out, t, group=self.group)
+
+    def all_gather(self, outs, t):
+        dist.all_gather(outs, t, group=self.group)
+
+
 def shard_bounds(n, world, rank):
     """Contiguous, balanced partition of range(n) into `world` blocks."""
     base, rem = divmod(n, world)
@@ -28,10 +46,13 @@ def shard_bounds(n, world, rank):
 
 class ShardedMapperEngine:
     def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, *, n_spots_total, device, precision="bf16x3",
-                 lambdas=None, group=None, fwd_splits=0, tile_size=0):
+                 lambdas=None, group=None, fwd_splits=0, tile_size=0, comm=None):
+        # `comm`: anything with world, rank, all_reduce, all_gather_into_tensor, all_gather (tests drive several shards of one
+        # GPU through an in-process communicator); default: the torch.distributed group
+        self.comm = comm if comm is not None else DistComm(group)
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.world = self.comm.world
+        self.rank = self.comm.rank
         self.lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0)
         self.lam.update(lambdas or {})
         self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, device=device,
@@ -44,20 +65,20 @@ class ShardedMapperEngine:
         self.x_pair = e.exchange_buffer(_capi.X_ROWPAIR)
         self.gathered = torch.empty(self.world * self.x_pair.numel(), dtype=torch.float32, device=e.device)
         # set-up exchange: |G_k|^2 over all spots, then the softmax statistics of the initial logits
-        dist.all_reduce(e.exchange_buffer(_capi.X_GNORM2), group=group)
+        self.comm.all_reduce(e.exchange_buffer(_capi.X_GNORM2))
         e.phase(0)
         self._exchange_row_stats()
 
     def _exchange_row_stats(self):
-        dist.all_gather_into_tensor(self.gathered, self.x_pair, group=self.group)
+        self.comm.all_gather_into_tensor(self.gathered, self.x_pair)
         self.eng.phase(4, gathered=self.gathered, nranks=self.world)
 
     def step(self, lr, history_row=None):
         e = self.eng
         e.phase(1)
-        dist.all_reduce(self.x_gene, group=self.group)
+        self.comm.all_reduce(self.x_gene)
         e.phase(2, history_row=history_row)
-        dist.all_reduce(self.x_rowq, group=self.group)
+        self.comm.all_reduce(self.x_rowq)
         e.phase(3, lr=lr, history_row=history_row)
         self._exchange_row_stats()
 
@@ -70,7 +91,7 @@ class ShardedMapperEngine:
         h = history.clone()
         add_cols = [_capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_L1, _capi.H_L2]
         part = torch.nan_to_num(h[:, add_cols], nan=0.0)
-        dist.all_reduce(part, group=self.group)
+        self.comm.all_reduce(part)
         lam = self.lam
         total = -lam["lambda_g1"] * h[:, _capi.H_MAIN]
         for col, key, sign in ((_capi.H_VG, "lambda_g2", -1.0), (_capi.H_KL, "lambda_d", 1.0),
@@ -93,13 +114,14 @@ class ShardedMapperEngine:
         pad = torch.zeros((P_local.shape[0], wmax), dtype=torch.float32, device=P_local.device)
         pad[:, :P_local.shape[1]] = P_local
         out = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(out, pad, group=self.group)
+        self.comm.all_gather(out, pad)
         return torch.cat([o[:, :w] for o, w in zip(out, widths)], dim=1)
 
 
-def make_sharded(S, G, M0, d=None, d_source=None, *, device, precision="bf16x3", lambdas=None, group=None, fwd_splits=0):
+def make_sharded(S, G, M0, d=None, d_source=None, *, device, precision="bf16x3", lambdas=None, group=None, fwd_splits=0, comm=None):
     """Slice full problem arrays (identical on every rank) into this rank's spot block."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    comm = comm if comm is not None else DistComm(group)
+    world, rank = comm.world, comm.rank
     V = G.shape[0]
     lo, hi = shard_bounds(V, world, rank)
     if hi - lo < 1:
@@ -112,4 +134,4 @@ def make_sharded(S, G, M0, d=None, d_source=None, *, device, precision="bf16x3",
         M_l = M_l.contiguous()
     d_l = None if d is None else d[lo:hi]
     return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, n_spots_total=V, device=device, precision=precision,
-                               lambdas=lambdas, group=group, fwd_splits=fwd_splits)
+                               lambdas=lambdas, group=group, fwd_splits=fwd_splits, comm=comm)

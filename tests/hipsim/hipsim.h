@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #if HIPSIM_ASM_SWITCH
@@ -263,8 +264,11 @@ inline void mfma16_f32(float a, float b, float* c4) {
     wave_barrier();
 }
 
+inline std::mutex& launch_mutex() { static std::mutex m; return m; }   // (not inside the template: one mutex for ALL kernels)
+
 template <class F>
 void launch(uint3s grid, uint3s block, F&& f) {
+    std::lock_guard<std::mutex> lock(launch_mutex());   // ONE emulated machine per process: launches from several host threads queue up
     Machine& m = M();
     m.gridDim = grid;
     m.blockDim = block;

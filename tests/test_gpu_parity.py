@@ -303,3 +303,42 @@ def test_concurrent_mappings_bit_identical():
         if len(a) == 3:
             np.testing.assert_array_equal(a[1], b[1])
         assert list(a[-1]["main_loss"]) == list(b[-1]["main_loss"])
+
+
+@pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "bf16x3"), (4, "bf16x3")])
+def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
+    """The multi-GPU driver (tangram_amd.sharded: phases + three exchanges per step) with `world` shards of one problem as
+    threads on ONE GPU (tests/local_comm.py instead of RCCL): same history and mapping as the unsharded engine and the fp64
+    oracle, with regularisers and a d_source prior, ragged shard widths."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import make_sharded
+    from tangram_amd import _capi
+    from tests.local_comm import run_ranks
+    C, K, V = 400, 48, 1010
+    data = orc.make_synthetic(C, K, V, seed=31)
+    M0 = orc.reference_init_M(C, V, 7)
+    rng = np.random.default_rng(3)
+    ds = rng.random(C).astype(np.float32); ds /= ds.sum()
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3, lambda_l1=1e-4, lambda_l2=1e-5)
+    n = 6
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], d_source=ds, device=DEV, precision=precision, lambdas=lam, comm=comm)
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist)
+        return sh.finalize_history(hist).cpu().numpy(), sh.result_full().cpu().numpy()
+
+    res = run_ranks(world, rank_fn)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], d_source=ds, device=DEV, precision=precision, lambdas=lam)
+    h1 = e.new_history(n)
+    e.step(n, 0.1, h1)
+    h1, P1 = h1.cpu().numpy(), e.result().cpu().numpy()
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], d_source=ds, M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(n, 0.1)
+    cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_L1, _capi.H_L2]
+    for hist, P in res:                                 # every rank holds the same reduced history and the full mapping
+        np.testing.assert_allclose(hist[:, cols], h1[:, cols], atol=5e-6, rtol=2e-6)
+        np.testing.assert_allclose(P, P1, atol=2e-6)
+        np.testing.assert_allclose(hist[:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
+        assert np.abs(P - Po).max() < 2e-5

@@ -174,3 +174,32 @@ def test_emulated_project_genes_constrained_filter(sim):
     S_all = rng.gamma(1.0, 2.0, size=(C, 16)).astype(np.float32)
     np.testing.assert_allclose(e.project_genes(S_all, unfiltered=True).numpy(), P.T @ S_all, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(e.project_genes(S_all, unfiltered=False).numpy(), P.T @ (S_all * F[:, None]), rtol=1e-5, atol=1e-6)
+
+
+def test_emulated_three_shards_in_threads(sim):
+    """tangram_amd.sharded with three spot shards as threads of this process (tests/local_comm.py; the gloo test in
+    test_sharded_gloo.py covers real process groups): same history and mapping as the unsharded engine."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import make_sharded
+    from oracle import tangram_oracle as orc
+    from tests.local_comm import run_ranks
+    from tangram_amd import _capi
+    C, K, V = 40, 12, 91
+    data = orc.make_synthetic(C, K, V, seed=2)
+    M0 = orc.reference_init_M(C, V, 3)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam, comm=comm)
+        h = sh.eng.new_history(3)
+        sh.run(3, 0.1, h)
+        return sh.finalize_history(h).numpy(), sh.result_full().numpy()
+
+    res = run_ranks(3, rank_fn)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam)
+    h1 = e.new_history(3)
+    e.step(3, 0.1, h1)
+    cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY]
+    for hist, P in res:
+        np.testing.assert_allclose(hist[:, cols], h1.numpy()[:, cols], atol=2e-6, rtol=1e-6)
+        np.testing.assert_allclose(P, e.result().numpy(), atol=1e-6)
