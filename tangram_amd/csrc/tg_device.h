@@ -94,9 +94,6 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 #endif
-#ifndef TG_GLDS
-#define TG_GLDS 1          // 1: K-contiguous operand tiles are staged with global_load_lds; 0: through registers
-#endif
 
 TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }
 TG_DEV float tg_bf16_hi_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed & 0xffff0000u); }

@@ -9,16 +9,17 @@
 //   dP = X + a_v w_c - lambda_r (log P + 1) ; r_c = sum_v P dP ; dM = P (dP - r) + l1/l2 terms
 //   Adam(M, dM)                                   (:373,:396)
 //
-// Kernel map (one iteration = 9 launches, no host synchronisation):
-//   tg_fwd_kernel        softmax-apply fused into the A-operand load of the MFMA GEMM P^T S (split over C)
-//   tg_ghat_reduce       sum the C-splits, per-gene / per-voxel cosine statistics partials
+// Kernel map (one iteration = 6 launches on one GPU without regularisers, no host synchronisation):
+//   tg_fwd_kernel        softmax-apply fused into the A-operand path of the MFMA GEMM P^T S (split over cell ranges)
+//   tg_ghat_reduce       sum the splits, per-gene / per-spot cosine statistics partials
 //   tg_gene_reduce       deterministic second stage of the per-gene statistics
-//   tg_loss_finalize     cos/KL scalars -> history row, alpha_k/beta_k, a_v
-//   tg_dghat_emit        dGhat in matrix-core operand format
-//   tg_bwd_kernel<1>     MFMA GEMM S dGhat^T fused with softmax-backward row dots r_c (partials)
-//   tg_rowsum_parts      r_c = sum of partials (+ entropy / L1 / L2 scalars into the history row)
-//   tg_bwd_kernel<2>     GEMM recomputed, fused with softmax backward + Adam + next-iteration softmax statistics
-//   tg_merge_stats       (max, sum exp) partials -> per-row shift and 1/Z for the next forward
+//   tg_dghat_emit        dGhat in matrix-core operand format (<SELF>: derives alpha_k, beta_k, a_v itself)
+//   tg_bwd_kernel        MFMA GEMM X = S dGhat^T, X stored as full row segments (+ row-dot partials on a spot shard)
+//   tg_adam_rowpass      one workgroup per cell row: row dot, softmax backward, Adam, statistics of the new row,
+//                        plus ONE extra workgroup that writes the history row (tg_loss_scalars)
+//   also: tg_loss_finalize (history + coefficients as a kernel of its own: spatial terms, spot shards),
+//   tg_rowsum_parts + tg_adam_update (two-kernel update: spot shards, rows > 16 384 spots), tg_hist_regs, tg_filter_kernel
+//   (MapperConstrained), tg_merge_stats, tg_spmm / tg_ct_* / tg_ac_* (spatial terms), tg_row_entropy / tg_val_finalize.
 //
 // Data layout in HBM: M, Adam m, Adam v are C x Vp fp32 row-major (Vp = V rounded up to 64);
 // S is kept twice in operand format: St [Kp][Cp] (cell index contiguous, for the forward contraction
@@ -111,28 +112,8 @@ struct TgMmaShape {
     static constexpr int NG = PR::KQ * (GE::FM / GA);         // groups per step = calls of the hook
 };
 
-// ROWS x 128-byte slab (one contraction step) of an operand stored as [row][step][128 B]
-template <int ROWS, int NT>
-struct TgKTile {
-    static constexpr int L = ROWS * 8 / NT;
-    u32x4 v[L];
-    TG_DEVM void load(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, int t) {
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const int idx = t + i * NT;
-            v[i] = *(const u32x4*)(base + (row0 + (idx >> 3)) * pitch_bytes + step * 128 + (idx & 7) * 16);
-        }
-    }
-    TG_DEVM void store(u32x4* tile, int t) const {
-#pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const int idx = t + i * NT, row = idx >> 3;
-            tile[row * 8 + tg_swz(row, idx & 7)] = v[i];
-        }
-    }
-};
-
-// The same slab copied by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.  The LDS image of one
+// ROWS x 128-byte slab (one contraction step) of an operand stored as [row][step][128 B], copied by LDS-DMA
+// (global_load_lds_dwordx4): no VGPR round trip, no ds_write.  The LDS image of one
 // wave instruction is lane-linear (64 x 16 B = 8 tile rows), so the XOR swizzle is applied to the per-lane SOURCE
 // address (logical chunk = physical chunk ^ swizzle(row)), the read side applies the same involution.
 // (`part` of `nparts`: the copies i = part, part + nparts, ... only -- for spreading the issue over the MFMA groups)
@@ -242,7 +223,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
 
     f32x4 mreg[RS];
     float sh[RS], mu[RS];
-    TgKTile<GE::TN, GE::NT> breg;
     const size_t bpitch = (size_t)a.nsteps * 128;
 
     auto load_m = [&](int step, int j) {                       // one float4 row of the M micro-block of `step`
@@ -262,7 +242,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < RS; ++j) load_m(step, j);
         load_sh(step);
-        if (!TG_GLDS) breg.load(a.St, (size_t)k0, bpitch, (size_t)step, t);
     };
     // the same global loads + the LDS-DMA of S^T as NITEM separate issues, spread over the first NSPREAD MFMA groups
     constexpr int GA_F = (PR::NP == 2 ? 1 : 2);                // the M staging registers leave room for small blocks only
@@ -320,11 +299,10 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     auto store_stage = [&](u32x4* st) {
         if (PR::NP == 2 && full_tile) store_stage_impl(st, std::false_type());     // (the second copy only pays off for bf16x3)
         else store_stage_impl(st, std::true_type());
-        if (!TG_GLDS) breg.store(st + GE::A_CHUNKS, t);
     };
 
     if (s_begin < s_end) {
-        if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)s_begin, lds + GE::A_CHUNKS, t, wave);
+        tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)s_begin, lds + GE::A_CHUNKS, t, wave);
         load_stage(s_begin);
         store_stage(lds);
         __syncthreads();
@@ -332,12 +310,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
             u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s - s_begin + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < s_end;
-            if (TG_GLDS && PR::NP == 2) {           // next step's global loads / LDS-DMA trickle in between the MFMA groups
+            if (PR::NP == 2) {                      // next step's global loads / LDS-DMA trickle in between the MFMA groups
                                                     // (bf16x3: -2 %; slower for the 8-row micro-blocks of bf16, profiles/r01/run26)
                 tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [&](int i) { if (more) issue_next(s + 1, nxt, i); });
             } else {
                 if (more) {
-                    if (TG_GLDS) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
+                    tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
                     load_stage(s + 1);
                 }
                 tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [](int) {});
@@ -752,7 +730,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
 
     {
         const size_t pitch = (size_t)nsteps * 128;
-#if TG_GLDS
         tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, 0, lds, t, wave);
         tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, 0, lds + GE::A_CHUNKS, t, wave);
         __syncthreads();
@@ -772,27 +749,6 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
             });
             __syncthreads();                        // drains the DMA (vmcnt) and releases `cur` for the step after next
         }
-#else
-        TgKTile<GE::TM, GE::NT> ra;
-        TgKTile<GE::TN, GE::NT> rb;
-        ra.load(a.dG, (size_t)v0, pitch, 0, t);
-        rb.load(a.Sk, (size_t)c0, pitch, 0, t);
-        ra.store(lds, t);
-        rb.store(lds + GE::A_CHUNKS, t);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
-            u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
-            const bool more = (s + 1) < nsteps;
-            if (more) {
-                ra.load(a.dG, (size_t)v0, pitch, (size_t)(s + 1), t);
-                rb.load(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), t);
-            }
-            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [](int) {});
-            if (more) { ra.store(nxt, t); rb.store(nxt + GE::A_CHUNKS, t); }
-            __syncthreads();
-        }
-#endif
     }
 
     // ---------------- epilogue ----------------
