@@ -275,9 +275,9 @@ static int tg_lds_attr() {
 #ifndef TG_SIM
     const int bytes = GE::LDS_BYTES;
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
 #endif
     return TG_OK;
 }
@@ -685,13 +685,13 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
     const int grid = tg_tilemap_grid(a.map);
     if (L.T == 256) {
-        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
-        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, stream, a);
+        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, stream, a);
     } else {
-        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
-        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
+        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, stream, a);
+        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, stream, a);
+        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, stream, a);
     }
 }
 

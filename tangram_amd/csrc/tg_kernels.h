@@ -49,6 +49,7 @@ struct TgGeo {
     static constexpr int FM = TM / (16 * WM), FN = TN / (16 * WN);
     static constexpr int A_CHUNKS = TM * 8, B_CHUNKS = TN * 8, STAGE_CHUNKS = A_CHUNKS + B_CHUNKS;
     static constexpr int STAGE_BYTES = STAGE_CHUNKS * 16, LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int BWD_LDS_BYTES = LDS_BYTES + TN * 16;            // + the per-cell constants of the row-dot epilogue
     static constexpr int LA = A_CHUNKS / NT, LB = B_CHUNKS / NT;       // 16-byte loads per thread per stage
     static_assert(NT == 2 * TM, "forward A staging assumes (TM/4 spot quads) x 8 chunk slots == NT threads");
     static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0 && FM % 4 == 0, "tile / thread mismatch");
@@ -752,140 +753,107 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     }
 
     // ---------------- epilogue ----------------
-    if constexpr (!ROWDOT) {
-        // single-GPU schedule: only X = S dGhat^T leaves the kernel; the row dots are taken by tg_adam_rowpass, which
-        // holds a whole row of M and X in registers (saves the M read, the exponentials and the partial-sum traffic here)
-        // The MFMA result layout gives a lane 4 consecutive spots of ONE cell (16 cells per wave instruction), i.e. 16 separate
-        // 64-byte pieces per store: ~13 us per tile, not overlapped with anything (one workgroup per CU).  The tile is
-        // therefore transposed through the (now idle) LDS in NPASS passes and leaves as full 1 KB row segments.
-        constexpr int RC = GE::TM / 4;                                        // 16-byte columns of a staged row (one cell, TM spots)
-        constexpr int CPP = (GE::LDS_BYTES / (GE::TM * 4) < GE::TN) ? GE::LDS_BYTES / (GE::TM * 4) : GE::TN;   // cells per pass
-        constexpr int NPASS = GE::TN / CPP, FPP = GE::FN / NPASS;             // passes, cell fragments per wave and pass
-        static_assert(FPP * NPASS == GE::FN && CPP == GE::WN * FPP * 16 && (CPP * RC) % GE::NT == 0 && RC >= 16, "epilogue staging geometry");
-        f32x4* stg = (f32x4*)tg_lds;
-        const int g = lane >> 4, r15 = lane & 15;
+    // The MFMA result layout gives a lane 4 consecutive spots of ONE cell (16 cells per wave instruction), i.e. 16 separate
+    // 64-byte pieces per global access: ~13 us per tile for the X store alone, not overlapped with anything (one workgroup
+    // per CU).  The tile is therefore transposed through the (now idle) LDS in NPASS passes of CPP cells and handled as
+    // full rows: RC lanes own the TM spots of one cell, X leaves (and M arrives) as 1 KB row segments.
+    //   ROWDOT == false (single GPU): only X leaves the kernel; the row dots are taken by tg_adam_rowpass.
+    //   ROWDOT == true  (spot shard, or rows too long for tg_adam_rowpass): also r_part[vt][c] = sum_{v in tile} P dP
+    //                    (+ the entropy / L1 / L2 / filter row sums when FULL), reduced over the RC lanes of the row.  The M
+    //                    segments of a whole pass are requested before the staging barrier (NIT loads in flight per lane);
+    //                    the per-cell constants of the tile wait in the 4 KB of LDS behind the staging area.
+    constexpr int RC = GE::TM / 4;                                        // 16-byte columns of a staged row (one cell, TM spots)
+    constexpr int CPP = (GE::LDS_BYTES / (GE::TM * 4) < GE::TN) ? GE::LDS_BYTES / (GE::TM * 4) : GE::TN;   // cells per pass
+    constexpr int NPASS = GE::TN / CPP, FPP = GE::FN / NPASS;             // passes, cell fragments per wave and pass
+    constexpr int NIT = (CPP * RC) / GE::NT;                              // row segments per lane and pass
+    static_assert(FPP * NPASS == GE::FN && CPP == GE::WN * FPP * 16 && (CPP * RC) % GE::NT == 0 && RC >= 16 && RC <= 64 && GE::NT % RC == 0,
+                  "epilogue staging geometry");
+    constexpr int NP = FULL ? (int)TGP1_N : 1;
+    f32x4* stg = (f32x4*)tg_lds;
+    f32x4* rowc = (f32x4*)(tg_lds + GE::LDS_BYTES);                       // ROWDOT: [TN] (shift, 1/Z, f, w) of the tile's cells
+    const int g = lane >> 4, r15 = lane & 15;
+    const int j = t % RC, v = v0 + 4 * j;                                 // this lane's 4 spots: the same in every row it visits
+    f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ROWDOT) {
+        if (t < GE::TN) {
+            const int c = c0 + t, cc = c < a.C ? c : a.C - 1;
+            rowc[t] = f32x4{a.rshift[cc], a.rinvz[cc], a.fgate ? a.fgate[cc] : 1.f, a.dens_w ? a.dens_w[cc] : 1.f};
+        }
+        aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
+    }
+    auto cell_of = [&](int pass, int row) {                               // staged row -> cell index of the tile (0 .. TN-1)
+        const int wn_r = row / (FPP * 16), rem = row % (FPP * 16);
+        return wn_r * (GE::TN / GE::WN) + (pass * FPP + rem / 16) * 16 + (rem & 15);
+    };
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            if (pass) __syncthreads();                                        // the previous pass has been read out
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass) __syncthreads();                                        // the previous pass has been read out
 #pragma unroll
-            for (int fjl = 0; fjl < FPP; ++fjl) {
-                const int cell_l = (wn * FPP + fjl) * 16 + r15;
+        for (int fjl = 0; fjl < FPP; ++fjl) {
+            const int cell_l = (wn * FPP + fjl) * 16 + r15;
 #pragma unroll
-                for (int fi = 0; fi < GE::FM; ++fi) {
-                    const int col = (wm * (GE::TM / GE::WM) + fi * 16) / 4 + g;
-                    stg[cell_l * RC + (col ^ r15)] = acc[fi][pass * FPP + fjl];   // XOR swizzle: the 16 cells of a lane group hit 16 different columns
-                }
+            for (int fi = 0; fi < GE::FM; ++fi) {
+                const int col = (wm * (GE::TM / GE::WM) + fi * 16) / 4 + g;
+                stg[cell_l * RC + (col ^ r15)] = acc[fi][pass * FPP + fjl];   // XOR swizzle: the 16 cells of a lane group hit 16 different columns
             }
-            __syncthreads();
+        }
+        f32x4 mqs[ROWDOT ? NIT : 1];
+        if constexpr (ROWDOT) {
 #pragma unroll
-            for (int it = 0; it < (CPP * RC) / GE::NT; ++it) {
-                const int idx = it * GE::NT + t, row = idx / RC, j = idx % RC;
-                const int wn_r = row / (FPP * 16), rem = row % (FPP * 16);
-                const int c = c0 + wn_r * (GE::TN / GE::WN) + (pass * FPP + rem / 16) * 16 + (rem & 15);
-                const int v = v0 + 4 * j;
-                if (c >= a.C || v >= a.Vp) continue;
-                const f32x4 x = stg[row * RC + (j ^ (row & 15))];
+            for (int it = 0; it < NIT; ++it) {
+                const int c = c0 + cell_of(pass, (it * GE::NT + t) / RC);
+                mqs[it] = *(const f32x4*)(a.M + (size_t)(c < a.C ? c : a.C - 1) * a.Vp + (v < a.Vp ? v : 0));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = (it * GE::NT + t) / RC;
+            const int cl = cell_of(pass, row), c = c0 + cl;
+            const bool ok = c < a.C && v < a.Vp;
+            const f32x4 x = stg[row * RC + (j ^ (row & 15))];
+            if (ok) {
                 if constexpr (PR::X16)
                     __builtin_nontemporal_store(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
                 else
                     __builtin_nontemporal_store(x, (f32x4*)((float*)a.X + (size_t)c * a.Vp + v));
             }
-        }
-        return;
-    } else {
-    float* red = (float*)tg_lds;        // LDS reuse: every wave is past the last barrier of the main loop
-    const int g = lane >> 4, r15 = lane & 15;
-    constexpr int NP = FULL ? (int)TGP1_N : 1;
-    constexpr int FM = GE::FM, FN = GE::FN;
-    constexpr int EB = GE::FM;                                 // spot quads whose global loads are in flight together (1 workgroup per CU: the epilogue needs its own memory-level parallelism)
-    const int vbase = v0 + wm * (GE::TM / GE::WM) + 4 * g;      // + fi * 16
-    float pacc[FN][NP];
-
+            if constexpr (ROWDOT) {
+                float pacc[NP];
 #pragma unroll
-    for (int fj = 0; fj < FN; ++fj) {
-        const int c = c0 + wn * (GE::TN / GE::WN) + fj * 16 + r15;
-        const bool cok = c < a.C;
-        const int cc = cok ? c : a.C - 1;
-        const float sh = a.rshift[cc], iz = a.rinvz[cc];
-        const float fg = a.fgate ? a.fgate[cc] : 1.f;
-        const float wc = a.dens_w ? a.dens_w[cc] : 1.f;
-        const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
-        {
-#pragma unroll
-            for (int q = 0; q < NP; ++q) pacc[fj][q] = 0.f;
-#pragma unroll
-            for (int fb = 0; fb < FM; fb += EB) {
-                f32x4 mq[EB], aq[EB];
-#pragma unroll
-                for (int f = 0; f < EB; ++f) {                 // issue the loads of this batch together
-                    const int v = vbase + (fb + f) * 16;
-                    mq[f] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + (v < a.Vp ? v : 0));
-                    aq[f] = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + (v < a.Vr ? v : 0));
-                }
-#pragma unroll
-                for (int f = 0; f < EB; ++f) {
-                    const int fi = fb + f, v = vbase + fi * 16;
-                    if (cok && v < a.Vp) {                                                        // X = S dGhat^T, kept for the update
-                        if constexpr (PR::X16)
-                            __builtin_nontemporal_store(u32x2{tg_pack_bf16(acc[fi][fj][0], acc[fi][fj][1]), tg_pack_bf16(acc[fi][fj][2], acc[fi][fj][3])},
-                                                        (u32x2*)((unsigned short*)a.X + (size_t)cc * a.Vp + v));
-                        else
-                            __builtin_nontemporal_store(acc[fi][fj], (f32x4*)((float*)a.X + (size_t)cc * a.Vp + v));
-                    }
+                for (int q = 0; q < NP; ++q) pacc[q] = 0.f;
+                if (ok) {
+                    const f32x4 mq = mqs[it], rcst = rowc[cl];
+                    const float sh = rcst[0], iz = rcst[1], fg = rcst[2], wc = rcst[3];
+                    const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (cok && (v + e) < a.V) {
-                            const float p = tg_exp(mq[f][e] - sh) * iz;
-                            const float x = acc[fi][fj][e];
-                            float dp = fg * (x + aq[f][e] * wc);
-                            if (FULL) {
-                                if (a.lambda_r != 0.f) {
-                                    const float lp = (mq[f][e] - sh) + logiz;      // log P, no underflow
-                                    dp -= a.lambda_r * (lp + 1.f);
-                                    pacc[fj][TGP1_ENT % NP] += p * lp;
-                                }
-                                pacc[fj][TGP1_Q % NP] += p * x;
-                                pacc[fj][TGP1_PA % NP] += p * aq[f][e];
-                                pacc[fj][TGP1_L1 % NP] += fabsf(mq[f][e]);
-                                pacc[fj][TGP1_L2 % NP] += mq[f][e] * mq[f][e];
+                        if ((v + e) >= a.V) continue;
+                        const float p = tg_exp(mq[e] - sh) * iz;
+                        float dp = fg * (x[e] + aq[e] * wc);
+                        if (FULL) {
+                            if (a.lambda_r != 0.f) {
+                                const float lp = (mq[e] - sh) + logiz;        // log P, no underflow
+                                dp -= a.lambda_r * (lp + 1.f);
+                                pacc[TGP1_ENT % NP] += p * lp;
                             }
-                            pacc[fj][TGP1_R] += p * dp;
+                            pacc[TGP1_Q % NP] += p * x[e];
+                            pacc[TGP1_PA % NP] += p * aq[e];
+                            pacc[TGP1_L1 % NP] += fabsf(mq[e]);
+                            pacc[TGP1_L2 % NP] += mq[e] * mq[e];
                         }
+                        pacc[TGP1_R] += p * dp;
                     }
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {                            // the RC lanes of this row segment sit in one wave
+                    float sm = pacc[q];
+#pragma unroll
+                    for (int m = RC / 2; m >= 1; m >>= 1) sm += tg_shfl_xor(sm, m);
+                    if (j == 0 && c < a.C) a.part[((size_t)vt * NP + q) * a.C + c] = sm;
                 }
             }
         }
-        // reduce over the 4 lane groups holding the same cell (different spots)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            float x = pacc[fj][q];
-            x += tg_shfl_xor(x, 16);
-            x += tg_shfl_xor(x, 32);
-            pacc[fj][q] = x;
-        }
-    }
-    // combine the WM waves along the spot axis through LDS, then one store per cell
-    __syncthreads();
-    if (g == 0) {
-#pragma unroll
-        for (int fj = 0; fj < FN; ++fj)
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                red[((wm * NP + q) * GE::TN) + wn * (GE::TN / GE::WN) + fj * 16 + r15] = pacc[fj][q];
-    }
-    __syncthreads();
-    if (t < GE::TN) {
-        const int c = c0 + t;
-        if (c < a.C) {
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                float sum = 0.f;
-#pragma unroll
-                for (int w = 0; w < GE::WM; ++w) sum += red[(w * NP + q) * GE::TN + t];
-                a.part[((size_t)vt * NP + q) * a.C + c] = sum;
-            }
-        }
-    }
     }
 }
 
