@@ -128,3 +128,52 @@ def test_train_score_invariant():
     G = data["G"].astype(np.float64)
     cs = [(a @ b) / (np.linalg.norm(a) * np.linalg.norm(b)) for a, b in zip(G.T, Gp.T)]
     assert round(float(np.mean(cs)), 3) == round(float(terms["main_loss"]), 3)
+
+
+def test_closed_form_gradient_equals_autograd_on_random_configurations():
+    """Property test (hypothesis): for random shapes, priors and hyper-parameters the closed-form gradient of the NumPy
+    oracle equals torch autograd on the port with the reference's op sequence (both in float64), and three Adam steps
+    agree.  Covers combinations the fixtures do not (e.g. d_source with regularisers, lambda_g2 = 0 with spatial terms)."""
+    import torch
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from oracle import torch_port as tp
+
+    lam_st = st.fixed_dictionaries(dict(
+        lambda_g2=st.sampled_from([0.0, 0.3, 1.0]), lambda_d=st.sampled_from([0.0, 0.5, 1.0, 2.0]),
+        lambda_r=st.sampled_from([0.0, 1e-3, 1e-2]), lambda_l1=st.sampled_from([0.0, 1e-4]),
+        lambda_l2=st.sampled_from([0.0, 1e-5]), lambda_neighborhood_g1=st.sampled_from([0.0, 0.96]),
+        lambda_ct_islands=st.sampled_from([0.0, 0.17])))
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(C=st.integers(2, 40), K=st.integers(1, 12), V=st.integers(2, 30), seed=st.integers(0, 10_000),
+           use_dsource=st.booleans(), lam=lam_st)
+    def check(C, K, V, seed, use_dsource, lam):
+        data = orc.make_synthetic(C, K, V, seed=seed, n_types=3)
+        rng = np.random.default_rng(seed)
+        M0 = rng.normal(size=(C, V)).astype(np.float32)      # (the reference keeps M as a float32 leaf)
+        kw = dict(lam)
+        d = data["d"] if kw["lambda_d"] > 0 else None
+        kw["d"] = d
+        if use_dsource and d is not None:
+            ds = rng.random(C) + 0.1
+            kw["d_source"] = (ds / ds.sum()).astype(np.float32)
+        if kw["lambda_neighborhood_g1"] > 0:
+            kw["voxel_weights"] = orc.grid_graph(V, standardized=True, self_inclusion=True)
+        if kw["lambda_ct_islands"] > 0:
+            kw["neighborhood_filter"] = orc.grid_graph(V, standardized=False, self_inclusion=False)
+            kw["ct_encode"] = data["ct_encode"]
+        o = orc.OracleMapper(data["S"], data["G"], M0=M0, dtype=np.float64, **kw)
+        terms, dM = o.loss_and_grad()
+        t = tp.TorchPortMapper(data["S"], data["G"], M0=M0, dtype=torch.float64, **kw)
+        total, out = t.loss()
+        total.backward()
+        g = t.M.grad.numpy()
+        assert abs(terms["total_loss"] - out["total_loss"]) <= 1e-10 * max(1.0, abs(out["total_loss"]))
+        assert np.abs(dM - g).max() <= 1e-10 * max(1.0, np.abs(g).max())
+        t2 = tp.TorchPortMapper(data["S"], data["G"], M0=M0, dtype=torch.float64, **kw)
+        P_o, h_o = o.train(3, 0.1)
+        P_t, h_t = t2.train(3, 0.1)
+        np.testing.assert_allclose(h_o["total_loss"], h_t["total_loss"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(P_o, P_t, atol=1e-7)
+
+    check()
