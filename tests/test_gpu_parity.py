@@ -342,3 +342,59 @@ def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
         np.testing.assert_allclose(P, P1, atol=2e-6)
         np.testing.assert_allclose(hist[:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
         assert np.abs(P - Po).max() < 2e-5
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_against_oracle(seed):
+    """Seeded random problems (shape, priors, every combination of loss terms incl. the CSR spatial ones, both mapper classes)
+    against the fp64 oracle, 4 iterations, fp32 and bf16x3 paths -- the combinations no fixture spells out."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    rng = np.random.default_rng(1000 + seed)
+    C, K, V = int(rng.integers(1, 300)), int(rng.integers(1, 70)), int(rng.integers(2, 400))
+    data = orc.make_synthetic(C, K, V, seed=seed, n_types=4)
+    M0 = rng.normal(size=(C, V)).astype(np.float32)
+    pick = lambda vals: float(rng.choice(vals))
+    constrained = seed % 4 == 3
+    n = 4
+    if constrained:
+        lam = dict(lambda_g1=1.0, lambda_d=pick([0.5, 1.0]), lambda_g2=pick([0.0, 0.5, 1.0]), lambda_r=pick([0.0, 1e-3]),
+                   lambda_count=pick([0.5, 1.0]), lambda_f_reg=pick([0.5, 1.0]))
+        F0 = rng.normal(size=(C,)).astype(np.float32)
+        target = float(rng.integers(1, max(2, C)))
+        mk_o = lambda: orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0, F0=F0, dtype=np.float64, target_count=target, **lam)
+        mk_e = lambda p: HipMapperEngine(data["S"], data["G"], M0, d=data["d"], F0=F0, mode="constrained", device=DEV, precision=p,
+                                         lambdas=lam, target_count=target)
+    else:
+        lam = dict(lambda_g1=1.0, lambda_d=pick([0.0, 0.5, 1.0, 2.0]), lambda_g2=pick([0.0, 0.4, 1.0]), lambda_r=pick([0.0, 1e-3, 1e-2]),
+                   lambda_l1=pick([0.0, 1e-4]), lambda_l2=pick([0.0, 1e-5]), lambda_neighborhood_g1=pick([0.0, 0.96]),
+                   lambda_ct_islands=pick([0.0, 0.17]), lambda_moran=pick([0.0, 0.0, 0.4]))
+        kw_o, kw_e = {}, {}
+        d = data["d"] if lam["lambda_d"] > 0 else None
+        if d is not None and rng.random() < 0.5:
+            ds = (rng.random(C) + 0.1).astype(np.float32)
+            ds /= ds.sum()
+            kw_o["d_source"] = kw_e["d_source"] = ds
+        if lam["lambda_neighborhood_g1"] > 0:
+            kw_o["voxel_weights"] = kw_e["voxel_weights"] = orc.grid_graph(V, standardized=True, self_inclusion=True)
+        if lam["lambda_ct_islands"] > 0:
+            kw_o["neighborhood_filter"] = kw_e["neighborhood_filter"] = orc.grid_graph(V, standardized=False, self_inclusion=False)
+            kw_o["ct_encode"] = kw_e["ct_encode"] = data["ct_encode"]
+        if lam["lambda_moran"] > 0:
+            kw_o["spatial_weights"] = kw_e["spatial_weights"] = orc.grid_graph(V, standardized=True, self_inclusion=False)
+        mk_o = lambda: orc.OracleMapper(data["S"], data["G"], d=d, M0=M0, dtype=np.float64, **lam, **kw_o)
+        mk_e = lambda p: HipMapperEngine(data["S"], data["G"], M0, d=d, device=DEV, precision=p, lambdas=lam, **kw_e)
+    res = mk_o().train(n, 0.1)
+    ho = np.array(res[-1]["total_loss"], dtype=np.float64)
+    for prec in ("fp32", "bf16x3"):
+        e = mk_e(prec)
+        hist = e.new_history(n)
+        e.step(n, 0.1, hist)
+        h = hist[:, _capi.H_TOTAL].cpu().numpy()
+        np.testing.assert_allclose(h, ho, atol=2e-5, rtol=2e-5, err_msg=f"{prec} {C}x{K}x{V} {lam}")
+        out = e.result(with_filter=constrained)
+        P = (out[0] if constrained else out).cpu().numpy()
+        np.testing.assert_allclose(P, res[0], atol=5e-5, err_msg=f"{prec} {C}x{K}x{V} {lam}")
+        if constrained:
+            np.testing.assert_allclose(out[1].cpu().numpy(), res[1], atol=5e-5)
