@@ -398,3 +398,31 @@ def test_random_configurations_against_oracle(seed):
         np.testing.assert_allclose(P, res[0], atol=5e-5, err_msg=f"{prec} {C}x{K}x{V} {lam}")
         if constrained:
             np.testing.assert_allclose(out[1].cpu().numpy(), res[1], atol=5e-5)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_empty_spots_and_zero_density(precision):
+    """Degenerate inputs the reference's formulas special-case: spots without any count (all-zero rows of G: the per-spot
+    cosine clamps both norms at 1e-8, torch semantics) and a density prior with exact zeros (KLDivLoss: xlogy(0, 0) = 0)."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    C, K, V = 150, 30, 260
+    data = orc.make_synthetic(C, K, V, seed=5)
+    G = data["G"].copy()
+    G[[0, 17, 255, 259]] = 0.0                                   # empty spots (first tile, tile edge, last rows)
+    d = (G.sum(1) / G.sum()).astype(np.float32)                  # -> exact zeros for them
+    assert (d == 0).sum() >= 4
+    M0 = orc.reference_init_M(C, V, 11)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=1.0, lambda_r=1e-3)
+    e = HipMapperEngine(data["S"], G, M0, d=d, device=DEV, precision=precision, lambdas=lam)
+    n = 6
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    o = orc.OracleMapper(data["S"], G, d=d, M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(n, 0.1)
+    h = hist.cpu().numpy()
+    assert np.isfinite(h[:, [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY]]).all()
+    for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss"), (_capi.H_VG, "vg_reg"), (_capi.H_KL, "kl_reg")):
+        np.testing.assert_allclose(h[:, col], np.array(ho[k]), atol=1e-5, rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(e.result().cpu().numpy(), Po, atol=2e-5)
