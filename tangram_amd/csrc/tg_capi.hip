@@ -882,7 +882,6 @@ extern "C" int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* histor
 
 template <class PR>
 static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, const float* gathered, int nranks) {
-    const TgLayout& L = m->L;
     int rc = TG_OK;
     switch (phase) {
         case 0: break;   // gnorm2 has been all-reduced in place by the caller; nothing else to do
