@@ -240,6 +240,7 @@ struct tg_mapper {
     tg_stream_t s_adam, s_fwd;                       // library-owned streams of the cell-band pipeline
     tg_event_t e_bwd[TG_MAX_BANDS], e_adam[TG_MAX_BANDS], e_fwd;
     // history scalars deferred from tg_launch_loss to one extra workgroup of the next update kernel (tg_dghat_emit<SELF>)
+    bool stream_once;                                // the per-iteration arrays exceed the MALL: non-temporal accesses (tg_ld_stream)
     bool fin_pending;
     TgFinalizeArgs fin_args;
     // profiling
@@ -275,9 +276,9 @@ static int tg_lds_attr() {
 #ifndef TG_SIM
     const int bytes = GE::LDS_BYTES;
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
-    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
+#define TG_BWD_ATTR(F, R, S) TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, F, R, S>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES))
+    TG_BWD_ATTR(false, true, true); TG_BWD_ATTR(true, true, true); TG_BWD_ATTR(false, false, true); TG_BWD_ATTR(false, false, false);
+#undef TG_BWD_ATTR
 #endif
     return TG_OK;
 }
@@ -502,6 +503,8 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
     m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false;
+    // M, Adam m, v (fp32) and X (fp32 or bf16) of this handle against the 256 MB MALL, with room left for the GEMM operands
+    m->stream_once = (size_t)L.C * L.Vp * (12 + (cfg->precision == TG_PREC_BF16 ? 2 : 4)) > ((size_t)192 << 20);
     m->s_adam = nullptr; m->s_fwd = nullptr;
     if (L.bands > 1) {
         int e = tg_stream_create(&m->s_adam) | tg_stream_create(&m->s_fwd) | tg_event_create(&m->e_fwd);
@@ -684,15 +687,19 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
     else { a.map = TgTileMap{0, L.nvt, nct}; a.map_major_is_cells = 0; }
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
     const int grid = tg_tilemap_grid(a.map);
+    // (the cached-access variant exists for the single-GPU X-only epilogue only: the row-dot variants serve spot shards and
+    //  very long rows, i.e. big problems, and every GEMM instantiation costs seconds of compile time)
+#define TG_BWD_GO(GE, F, R, S) TG_LAUNCH((tg_bwd_kernel<PR, GE, F, R, S>), grid, 1, GE::NT, GE::BWD_LDS_BYTES, stream, a)
     if (L.T == 256) {
-        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, false>), grid, 1, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, stream, a);
-        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, true, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoLarge, false, true>), grid, 1, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, stream, a);
+        if (x_only) { if (m->stream_once) TG_BWD_GO(TgGeoLarge, false, false, true); else TG_BWD_GO(TgGeoLarge, false, false, false); }
+        else if (L.full) TG_BWD_GO(TgGeoLarge, true, true, true);
+        else TG_BWD_GO(TgGeoLarge, false, true, true);
     } else {
-        if (x_only) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, false>), grid, 1, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, stream, a);
-        else if (L.full) TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, true, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, stream, a);
-        else TG_LAUNCH((tg_bwd_kernel<PR, TgGeoSmall, false, true>), grid, 1, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, stream, a);
+        if (x_only) { if (m->stream_once) TG_BWD_GO(TgGeoSmall, false, false, true); else TG_BWD_GO(TgGeoSmall, false, false, false); }
+        else if (L.full) TG_BWD_GO(TgGeoSmall, true, true, true);
+        else TG_BWD_GO(TgGeoSmall, false, true, true);
     }
+#undef TG_BWD_GO
 }
 
 static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1) {
@@ -728,16 +735,16 @@ static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
 
 // streaming softmax-backward + Adam over the cells [c0, c1); `finalize`: write the next softmax statistics directly
 // (single GPU, no filter)
-template <bool FULL, bool X16>
+template <bool FULL, bool X16, bool STREAM>
 static void tg_launch_rowpass(const TgUpdateArgs& u, int rows, int V, tg_stream_t stream) {
-#define TG_RP(NQ, NT) TG_LAUNCH((tg_adam_rowpass<FULL, X16, NQ, NT>), rows, 1, NT, 256, stream, u)
+#define TG_RP(NQ, NT, S) TG_LAUNCH((tg_adam_rowpass<FULL, X16, NQ, NT, S>), rows, 1, NT, 256, stream, u)
     if (V <= 4096) {                                  // 256 threads, up to 4 quads each
         const int nq = (V + 1023) / 1024;
-        if (nq <= 1) TG_RP(1, 256); else if (nq <= 2) TG_RP(2, 256); else TG_RP(4, 256);
-    } else {                                          // 512 threads, up to 8 quads each (V <= TG_ROWPASS_MAX_V)
-        const int nq = (V + 2047) / 2048;
-        if (nq <= 3) TG_RP(3, 512); else if (nq <= 4) TG_RP(4, 512); else if (nq <= 5) TG_RP(5, 512);
-        else if (nq <= 6) TG_RP(6, 512); else TG_RP(8, 512);
+        if (nq <= 1) TG_RP(1, 256, STREAM); else if (nq <= 2) TG_RP(2, 256, STREAM); else TG_RP(4, 256, STREAM);
+    } else {                                          // 512 threads, up to 8 quads each (V <= TG_ROWPASS_MAX_V); streaming accesses
+        const int nq = (V + 2047) / 2048;             // only: with rows this long the cached variant would serve a few hundred cells
+        if (nq <= 3) TG_RP(3, 512, true); else if (nq <= 4) TG_RP(4, 512, true); else if (nq <= 5) TG_RP(5, 512, true);
+        else if (nq <= 6) TG_RP(6, 512, true); else TG_RP(8, 512, true);
     }
 #undef TG_RP
 }
@@ -767,13 +774,18 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     int extra_wg = 0;
     if (m->fin_pending && whole) { u.fin = m->fin_args; u.fin_on = 1; extra_wg = 1; m->fin_pending = false; }
     if (rowpass) {
-        if (L.full) { if (x16) tg_launch_rowpass<true, true>(u, c1 - c0 + extra_wg, L.V, stream); else tg_launch_rowpass<true, false>(u, c1 - c0 + extra_wg, L.V, stream); }
-        else { if (x16) tg_launch_rowpass<false, true>(u, c1 - c0 + extra_wg, L.V, stream); else tg_launch_rowpass<false, false>(u, c1 - c0 + extra_wg, L.V, stream); }
+#define TG_RPGO(F, X) do { if (m->stream_once) tg_launch_rowpass<F, X, true>(u, c1 - c0 + extra_wg, L.V, stream); \
+                           else tg_launch_rowpass<F, X, false>(u, c1 - c0 + extra_wg, L.V, stream); } while (0)
+        if (L.full) { if (x16) TG_RPGO(true, true); else TG_RPGO(true, false); }
+        else { if (x16) TG_RPGO(false, true); else TG_RPGO(false, false); }
+#undef TG_RPGO
         if (whole) tg_prof_mark(m, "tg_adam_rowpass");
         return TG_OK;
     }
-    if (L.full) { if (x16) TG_LAUNCH((tg_adam_update<true, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); else TG_LAUNCH((tg_adam_update<true, false>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); }
-    else { if (x16) TG_LAUNCH((tg_adam_update<false, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); else TG_LAUNCH((tg_adam_update<false, false>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); }
+#define TG_AUGO(F, X) TG_LAUNCH((tg_adam_update<F, X, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u)
+    if (L.full) { if (x16) TG_AUGO(true, true); else TG_AUGO(true, false); }
+    else { if (x16) TG_AUGO(false, true); else TG_AUGO(false, false); }
+#undef TG_AUGO
     if (whole) tg_prof_mark(m, "tg_adam_update");
     return TG_OK;
 }

@@ -27,6 +27,17 @@
 #pragma once
 #include "tg_device.h"
 
+// Loads / stores of the arrays that are streamed once per iteration (M, X, Adam m, v).  STREAM (compile time; a run-time
+// `flag ? nontemporal_load : load` makes hipcc issue BOTH loads and select): non-temporal, so that 8.4 GB per iteration do
+// not churn L2 / MALL (-9 % on the update kernel at 30k x 10k); problems whose four arrays fit the 256 MB MALL keep ordinary
+// accesses and find M still cached in the next forward pass (+5 % there, profiles/r01 run34).
+template <bool STREAM, class T> TG_DEV T tg_ld_stream(const T* p) {
+    if constexpr (STREAM) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool STREAM, class T> TG_DEV void tg_st_stream(const T& v, T* p) {
+    if constexpr (STREAM) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 #define TG_NEG_BIG (-3.0e38f)
 #define TG_COS_EPS 1e-8f
 
@@ -711,7 +722,7 @@ struct TgBwdArgs {
 };
 enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
 
-template <class PR, class GE, bool FULL, bool ROWDOT>
+template <class PR, class GE, bool FULL, bool ROWDOT, bool STREAM>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
@@ -814,9 +825,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
             const f32x4 x = stg[row * RC + (j ^ (row & 15))];
             if (ok) {
                 if constexpr (PR::X16)
-                    __builtin_nontemporal_store(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
+                    tg_st_stream<STREAM>(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
                 else
-                    __builtin_nontemporal_store(x, (f32x4*)((float*)a.X + (size_t)c * a.Vp + v));
+                    tg_st_stream<STREAM>(x, (f32x4*)((float*)a.X + (size_t)c * a.Vp + v));
             }
             if constexpr (ROWDOT) {
                 float pacc[NP];
@@ -1165,7 +1176,7 @@ struct TgUpdateArgs {
     TgFinalizeArgs fin;                               //    (tg_loss_scalars; see tg_dghat_emit<SELF>)
 };
 
-template <bool FULL, bool X16>
+template <bool FULL, bool X16, bool STREAM>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [4 waves][2]  (history workgroup: [4][5])
@@ -1180,15 +1191,15 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     for (int v = 4 * t; v < a.V; v += 1024) {
         f32x4 xq;
         if constexpr (X16) {
-            const u32x2 xp = __builtin_nontemporal_load((const u32x2*)((const unsigned short*)a.X + row + v));
+            const u32x2 xp = tg_ld_stream<STREAM>((const u32x2*)((const unsigned short*)a.X + row + v));
             xq = f32x4{tg_bf16_lo_to_f32(xp[0]), tg_bf16_hi_to_f32(xp[0]), tg_bf16_lo_to_f32(xp[1]), tg_bf16_hi_to_f32(xp[1])};
         } else {
-            xq = __builtin_nontemporal_load((const f32x4*)((const float*)a.X + row + v));
+            xq = tg_ld_stream<STREAM>((const f32x4*)((const float*)a.X + row + v));
         }
         // (streamed once per iteration: non-temporal accesses keep these 8.4 GB from churning L2 / MALL; measured -9 %)
-        f32x4 mq = __builtin_nontemporal_load((const f32x4*)(a.M + row + v));
-        f32x4 m1 = __builtin_nontemporal_load((const f32x4*)(a.am + row + v));
-        f32x4 m2 = __builtin_nontemporal_load((const f32x4*)(a.av + row + v));
+        f32x4 mq = tg_ld_stream<STREAM>((const f32x4*)(a.M + row + v));
+        f32x4 m1 = tg_ld_stream<STREAM>((const f32x4*)(a.am + row + v));
+        f32x4 m2 = tg_ld_stream<STREAM>((const f32x4*)(a.av + row + v));
         const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + v);
         float nm[4];
         float qmax = TG_NEG_BIG;
@@ -1210,9 +1221,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
             if (ok) { mq[e] = mn; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mn); }
             nm[e] = ok ? mn : TG_NEG_BIG;
         }
-        __builtin_nontemporal_store(mq, (f32x4*)(a.M + row + v));
-        __builtin_nontemporal_store(m1, (f32x4*)(a.am + row + v));
-        __builtin_nontemporal_store(m2, (f32x4*)(a.av + row + v));
+        tg_st_stream<STREAM>(mq, (f32x4*)(a.M + row + v));
+        tg_st_stream<STREAM>(m1, (f32x4*)(a.am + row + v));
+        tg_st_stream<STREAM>(m2, (f32x4*)(a.av + row + v));
         const float nmx = tg_fmax(lmax, qmax);
         float qs = 0.f;
 #pragma unroll
@@ -1252,7 +1263,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
 //   pass 1: P, dP -> r_c (block reduction; plus the entropy / L1 / L2 / filter row sums when FULL),
 //   pass 2: dM = P (dP - r_c), Adam, stores, (max, sum exp) of the new row.
 // HBM traffic is that of tg_adam_update; tg_bwd_kernel no longer reads M nor writes row-dot partials.
-template <bool FULL, bool X16, int NQ, int NT>
+template <bool FULL, bool X16, int NQ, int NT, bool STREAM>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(TgUpdateArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [NW waves][TGP1_N] then [NW][2]
@@ -1277,17 +1288,17 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(
     for (int q = 0; q < NQ; ++q) {
         const int v = 4 * (t + NT * q);
         const int vl = v < a.V ? v : 0;
-        mq[q] = __builtin_nontemporal_load((const f32x4*)(a.M + row + vl));      // streamed once: non-temporal (see tg_adam_update)
-        if constexpr (X16) xr[q] = __builtin_nontemporal_load((const u32x2*)((const unsigned short*)a.X + row + vl));
-        else xr[q] = __builtin_nontemporal_load((const f32x4*)((const float*)a.X + row + vl));
+        mq[q] = tg_ld_stream<STREAM>((const f32x4*)(a.M + row + vl));      // streamed once: non-temporal (see tg_adam_update)
+        if constexpr (X16) xr[q] = tg_ld_stream<STREAM>((const u32x2*)((const unsigned short*)a.X + row + vl));
+        else xr[q] = tg_ld_stream<STREAM>((const f32x4*)((const float*)a.X + row + vl));
     }
     f32x4 m1q[NQ], m2q[NQ];                              // the moments travel while pass 1 computes
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int v = 4 * (t + NT * q);
         const int vl = v < a.V ? v : 0;
-        m1q[q] = __builtin_nontemporal_load((const f32x4*)(a.am + row + vl));
-        m2q[q] = __builtin_nontemporal_load((const f32x4*)(a.av + row + vl));
+        m1q[q] = tg_ld_stream<STREAM>((const f32x4*)(a.am + row + vl));
+        m2q[q] = tg_ld_stream<STREAM>((const f32x4*)(a.av + row + vl));
     }
     float acc[NP];
 #pragma unroll
@@ -1365,9 +1376,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(
             if (ok) { mo4[e] = mn; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mn); }
             nm[e] = ok ? mn : TG_NEG_BIG;
         }
-        __builtin_nontemporal_store(mo4, (f32x4*)(a.M + row + v));
-        __builtin_nontemporal_store(m1, (f32x4*)(a.am + row + v));
-        __builtin_nontemporal_store(m2, (f32x4*)(a.av + row + v));
+        tg_st_stream<STREAM>(mo4, (f32x4*)(a.M + row + v));
+        tg_st_stream<STREAM>(m1, (f32x4*)(a.am + row + v));
+        tg_st_stream<STREAM>(m2, (f32x4*)(a.av + row + v));
         const float nmx = tg_fmax(lmax, qmax);
         float qs = 0.f;
 #pragma unroll
