@@ -99,6 +99,25 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
     };
     load_b(0, 0);
     load_a(0, 0, 0);
+    if constexpr (PR::NP == 2 && PR::KQ == 1 && GE::FN == 4) {
+        // bf16x3: the GA * 2 fragment loads of the next group are issued one per GA * 2-th of this group's MFMAs (6 MFMAs each)
+        // instead of all in front of them (backward -1.7 %, profiles/r01 run40)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+#pragma unroll
+            for (int sub = 0; sub < 2 * GA; ++sub) {
+                const int fi = sub >> 1;
+                if (i + 1 < NG) a[(i + 1) & 1][fi][sub & 1] = sa[((i + 1) * GA + fi) * 128 + ((4 * (sub & 1) + g) ^ swr ^ (((i + 1) * GA + fi) & 1))];
+                if (sub == 0) hook(i);
+                TG_SCHED_FENCE();
+#pragma unroll
+                for (int fj = 2 * (sub & 1); fj < 2 * (sub & 1) + 2; ++fj)
+                    acc[i * GA + fi][fj] = PR::mma(a[i & 1][fi], b[0][fj], acc[i * GA + fi][fj]);
+                TG_SCHED_FENCE();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
         const int q = i / NB, blk = i % NB;
