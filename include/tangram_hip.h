@@ -160,6 +160,12 @@ int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev);
 int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t ld_s, int32_t n_genes, float* out_dev,
                             int64_t ld_out, int32_t unfiltered);
 
+/* Replaces `adata_sc.X.toarray()` on the host (utils.py:364-365; mapping_utils.py:259-266): the dense block of gene columns
+ * [col0, col0 + n_cols) of a cells x genes CSR matrix (int64 indptr [n_rows + 1], int32 indices, float data, all on the device),
+ * written to out_dev[n_rows][ld_out].  No handle: enqueued on `hip_stream`.  Feeds tg_mapper_project_genes block by block.  */
+int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_dev, const float* data_dev, int64_t n_rows,
+                            int32_t col0, int32_t n_cols, float* out_dev, int64_t ld_out, void* hip_stream);
+
 /* Replaces Mapper._val_loss_fn (mapping_optimizer.py:311-356), evaluated with the CURRENT logits:
  * out4_dev = { gene score + voxel score, gene score, sparsity-weighted gene score, normalised map entropy }.   */
 int tg_mapper_validate(tg_mapper* m, float* out4_dev);

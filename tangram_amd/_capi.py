@@ -63,6 +63,8 @@ def _declare(lib):
     lib.tg_mapper_result.argtypes = [vp, vp, vp]
     lib.tg_mapper_project.argtypes = [vp, vp]
     lib.tg_mapper_project_genes.argtypes = [vp, vp, ct.c_int64, i32, vp, ct.c_int64, i32]
+    lib.tg_csr_columns_to_dense.argtypes = [vp, vp, vp, ct.c_int64, i32, i32, vp, ct.c_int64, vp]
+    lib.tg_csr_columns_to_dense.restype = i32
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
     lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
@@ -79,7 +81,7 @@ def _declare(lib):
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
            "tg_mapper_step", "tg_mapper_phase", "tg_mapper_exchange_buffer", "tg_mapper_result",
-           "tg_mapper_project", "tg_mapper_project_genes", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
+           "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
            "tg_mapper_profile_read", "tg_mapper_validate"]
 
 

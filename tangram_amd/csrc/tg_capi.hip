@@ -1013,6 +1013,17 @@ extern "C" int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t
     return TG_OK;
 }
 
+extern "C" int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_dev, const float* data_dev, int64_t n_rows,
+                                       int32_t col0, int32_t n_cols, float* out_dev, int64_t ld_out, void* hip_stream) {
+    if (!indptr_dev || !indices_dev || !data_dev || !out_dev) return tg_fail(TG_ERR_INVALID, "null argument");
+    if (n_rows < 1 || n_cols < 1 || col0 < 0 || ld_out < n_cols) return tg_fail(TG_ERR_INVALID, "bad block: rows %lld, columns %d at %d, pitch %lld",
+                                                                                 (long long)n_rows, n_cols, col0, (long long)ld_out);
+    TG_LAUNCH(tg_csr_cols_to_dense, n_rows, 1, 256, 0, (tg_stream_t)hip_stream, (const long long*)indptr_dev, (const int*)indices_dev, data_dev,
+              col0, n_cols, out_dev, (long long)ld_out);
+    TG_CK(tg_check_launch());
+    return TG_OK;
+}
+
 extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (!out4_dev) return tg_fail(TG_ERR_INVALID, "out is NULL");

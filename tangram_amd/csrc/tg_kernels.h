@@ -1741,6 +1741,21 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_colsum_parts(const float* part, int npar
     out[k] = s * scale;
 }
 
+// Dense block of gene columns [col0, col0 + ncols) of a CSR matrix (cells x genes, as AnnData keeps adata_sc.X): one workgroup
+// per cell row; replaces `adata_sc.X.toarray()` on the host (utils.py:364-365, mapping_utils.py:259-266) for project_genes.
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_csr_cols_to_dense(const long long* indptr, const int* indices, const float* data, int col0,
+                                                          int ncols, float* out, long long ld_out) {
+    const long long row = blockIdx.x;
+    float* o = out + row * ld_out;
+    for (int k = threadIdx.x; k < ncols; k += 256) o[k] = 0.f;
+    __syncthreads();
+    const long long beg = indptr[row], end = indptr[row + 1];
+    for (long long i = beg + threadIdx.x; i < end; i += 256) {
+        const int c = indices[i] - col0;
+        if (c >= 0 && c < ncols) o[c] = data[i];           // (canonical CSR: one entry per (row, column))
+    }
+}
+
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fill(float* p, size_t n, float val) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = val;

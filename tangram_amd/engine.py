@@ -121,8 +121,9 @@ class HipMapperEngine:
         self.state = torch.empty(sizes.state_bytes, dtype=torch.uint8, device=self.device)
         self.workspace = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
         handle = ct.c_void_p()
+        self._hip_stream = self._stream()              # the stream every call of this handle is enqueued on
         self._call(self._lib.tg_mapper_create, ct.byref(cfg), ct.byref(inp), self.state.data_ptr(),
-                   self.workspace.data_ptr(), self._stream(), ct.byref(handle))
+                   self.workspace.data_ptr(), self._hip_stream, ct.byref(handle))
         self._h = handle
         self._sync()            # inputs were only borrowed for the duration of create()
         self._scratch_row = torch.zeros(_capi.H_NTERMS, dtype=torch.float32, device=self.device)
@@ -189,8 +190,12 @@ class HipMapperEngine:
         return Gh
 
     def project_genes(self, S_all, unfiltered=True):
-        """softmax(M)^T S_all for ANY gene set ([C, K_all] float32 on this device or host array) -> [V, K_all] device
-        tensor; the C x V mapping never leaves the GPU (reference: `adata_map.X.T @ adata_sc.X`, utils.py:366-368)."""
+        """softmax(M)^T S_all for ANY gene set -> [V, K_all] device tensor; the C x V mapping never leaves the GPU
+        (reference: `adata_map.X.T @ adata_sc.X`, utils.py:366-368).  S_all: [C, K_all] float32 on this device, a host array,
+        or a scipy.sparse matrix -- then the CSR arrays are uploaded once and every block of genes is expanded on the device
+        (tg_csr_columns_to_dense) instead of `adata_sc.X.toarray()` on the host (utils.py:364-365)."""
+        if hasattr(S_all, "tocsr") and not isinstance(S_all, torch.Tensor):
+            return self._project_genes_csr(S_all.tocsr(), unfiltered)
         S_all = torch.as_tensor(S_all)
         if S_all.dim() != 2 or S_all.shape[0] != self.C:
             raise ValueError("S_all must be [n_cells, n_genes] with the mapper's cells")
@@ -201,6 +206,24 @@ class HipMapperEngine:
         out = torch.empty((self.V, n), dtype=torch.float32, device=self.device)
         self._call(self._lib.tg_mapper_project_genes, self._h, S_all.data_ptr(), int(S_all.stride(0)), n, out.data_ptr(), n,
                    1 if unfiltered else 0)
+        return out
+
+    def _project_genes_csr(self, csr, unfiltered):
+        if csr.shape[0] != self.C:
+            raise ValueError("S_all must be [n_cells, n_genes] with the mapper's cells")
+        csr.sum_duplicates()                                         # canonical form: one entry per (row, column)
+        n = int(csr.shape[1])
+        indptr = torch.as_tensor(np.asarray(csr.indptr, dtype=np.int64), device=self.device)
+        indices = torch.as_tensor(np.asarray(csr.indices, dtype=np.int32), device=self.device)
+        data = torch.as_tensor(np.asarray(csr.data, dtype=np.float32), device=self.device)
+        out = torch.empty((self.V, n), dtype=torch.float32, device=self.device)
+        block = torch.empty((self.C, min(self.K, n)), dtype=torch.float32, device=self.device)
+        for k0 in range(0, n, self.K):
+            kc = min(self.K, n - k0)
+            self._call(self._lib.tg_csr_columns_to_dense, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), self.C, k0, kc,
+                       block.data_ptr(), int(block.stride(0)), self._hip_stream)
+            self._call(self._lib.tg_mapper_project_genes, self._h, block.data_ptr(), int(block.stride(0)), kc,
+                       out.data_ptr() + 4 * k0, n, 1 if unfiltered else 0)
         return out
 
     def validate(self):

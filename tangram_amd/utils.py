@@ -76,7 +76,8 @@ def project_genes(adata_map, adata_sc, cluster_label=None, scale=True, *, mapper
         adata_sc = mu.adata_to_cluster_expression(adata_sc, cluster_label, scale=scale)
     if not adata_map.obs.index.equals(adata_sc.obs.index):                           # :362-363
         raise ValueError("The two AnnDatas need to have same `obs` index.")
-    S_all = np.ascontiguousarray(mu._dense(adata_sc.X), dtype=np.float32)            # :364-365
+    X_sc = adata_sc.X                                                                # :364-365: sparse stays sparse, the gene blocks
+    S_all = X_sc if hasattr(X_sc, "tocsr") else np.ascontiguousarray(mu._dense(X_sc), dtype=np.float32)   # are expanded on the device
     if mapper is None:
         mapper = getattr(adata_map, "_tangram_amd_mapper", None)
     engine = mapper._engine if mapper is not None else _projection_engine(adata_map, torch.device(device), gemm_precision)

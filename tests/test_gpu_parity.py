@@ -426,3 +426,21 @@ def test_empty_spots_and_zero_density(precision):
     for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss"), (_capi.H_VG, "vg_reg"), (_capi.H_KL, "kl_reg")):
         np.testing.assert_allclose(h[:, col], np.array(ho[k]), atol=1e-5, rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(e.result().cpu().numpy(), Po, atol=2e-5)
+
+
+def test_project_genes_from_sparse_single_cell_matrix():
+    """f-4: project_genes fed with the scipy CSR `adata_sc.X` (no toarray() on the host): bit-identical to the dense path, through
+    the engine and through tangram_amd.project_genes."""
+    import scipy.sparse as sp
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.synthetic import make_workload, init_logits
+    C, K, V, K_all = 2000, 150, 700, 1234
+    w = make_workload(C, K, V, DEV, seed=5)
+    e = HipMapperEngine(w["S"], w["G"], init_logits(C, V, DEV, seed=2), d=w["d"], device=DEV, precision="bf16x3", lambdas=dict(lambda_d=1.0))
+    e.step(4, 0.1, e.new_history(4))
+    rng = np.random.default_rng(0)
+    dense = (rng.gamma(1.0, 2.0, size=(C, K_all)) * (rng.random((C, K_all)) < 0.1)).astype(np.float32)
+    a = e.project_genes(sp.csr_matrix(dense)).cpu().numpy()
+    b = e.project_genes(dense).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (V, K_all) and np.isfinite(a).all() and a.max() > 0

@@ -203,3 +203,24 @@ def test_emulated_three_shards_in_threads(sim):
     for hist, P in res:
         np.testing.assert_allclose(hist[:, cols], h1.numpy()[:, cols], atol=2e-6, rtol=1e-6)
         np.testing.assert_allclose(P, e.result().numpy(), atol=1e-6)
+
+
+def test_emulated_project_genes_from_csr(sim):
+    """project_genes with a scipy CSR single-cell matrix: the gene blocks are expanded on the device (tg_csr_columns_to_dense)
+    and must give exactly the dense path's result (reference: adata_sc.X.toarray() on the host, utils.py:364-365)."""
+    import scipy.sparse as sp
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V, K_all = 50, 8, 21, 29
+    data = orc.make_synthetic(C, K, V, seed=23)
+    rng = np.random.default_rng(7)
+    e = HipMapperEngine(data["S"], data["G"], rng.normal(size=(C, V)).astype(np.float32), d=data["d"], device="cpu",
+                        precision="fp32", lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+    e.step(2, 0.1, e.new_history(2))
+    dense = (rng.gamma(1.0, 2.0, size=(C, K_all)) * (rng.random((C, K_all)) < 0.3)).astype(np.float32)
+    dense[3] = 0.0                                               # an empty row
+    for fmt in (sp.csr_matrix, sp.csc_matrix, sp.coo_matrix):
+        out = e.project_genes(fmt(dense)).numpy()
+        np.testing.assert_array_equal(out, e.project_genes(dense).numpy())
+    with pytest.raises(ValueError):
+        e.project_genes(sp.csr_matrix(dense[:-1]))
