@@ -23,7 +23,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK = 8.0e12                      # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
-MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15, "fp32": 157.3e12}   # dense matrix-core peak of the operand dtype
+# dense matrix-core peak for ONE algorithmic product: bf16 2.5 PFLOP/s; split-bf16 x3 issues three bf16 MFMAs per product, i.e.
+# 833 TFLOP/s effective (the figure SURVEY 8(d) prices the bf16x3 roofline with); exact f32 MFMA 157.3 TFLOP/s
+MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15 / 3.0, "fp32": 157.3e12}
 DTYPE_NAME = {"bf16x3": "f32 (split-bf16 x3 MFMA operands, f32 accumulate and state: fp32-parity)",
               "bf16": "bf16 MFMA operands, f32 accumulate and state", "fp32": "f32 (exact f32 MFMA)"}
 WORKLOADS = {"cfg2": (30000, 1000, 10000)}
