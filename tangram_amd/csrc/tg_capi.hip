@@ -22,7 +22,9 @@ static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch,
 }
 static int tg_memset(void* dst, int v, size_t n, tg_stream_t) { memset(dst, v, n); return 0; }
 static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t) { memcpy(dst, src, n); return 0; }
-static int tg_check_launch() { return 0; }
+static int tg_launch_error(const char** name) { *name = nullptr; return 0; }
+static bool tg_launch_failed() { return false; }
+static const char* tg_hip_errstr(int) { return "emulator"; }
 typedef int tg_event_t;
 static int tg_stream_create(tg_stream_t* s) { *s = nullptr; return 0; }
 static void tg_stream_destroy(tg_stream_t) {}
@@ -32,8 +34,26 @@ static void tg_event_record(tg_event_t, tg_stream_t) {}           // the emulato
 static void tg_stream_wait(tg_stream_t, tg_event_t) {}
 #else
 typedef hipStream_t tg_stream_t;
-#define TG_LAUNCH(kern, gx, gy, block, lds, stream, ...) \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy), 1), dim3((unsigned)(block), 1, 1), (size_t)(lds), stream, __VA_ARGS__)
+// Every launch is checked where it is issued: the FIRST failing kernel of a call is remembered by name (thread-local) and
+// reported by tg_launch_status() -- a failed launch in the middle of a step is no longer an anonymous error at its end.
+static thread_local int g_launch_rc = 0;
+static thread_local const char* g_launch_name = nullptr;
+#define TG_LAUNCH(kern, gx, gy, block, lds, stream, ...)                                                                          \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy), 1), dim3((unsigned)(block), 1, 1), (size_t)(lds), stream,   \
+                           __VA_ARGS__);                                                                                          \
+        const int _le = (int)hipGetLastError();                                                                                   \
+        if (_le != 0 && g_launch_rc == 0) { g_launch_rc = _le; g_launch_name = #kern; }                                           \
+    } while (0)
+static int tg_launch_error(const char** name) {
+    int e = g_launch_rc;
+    *name = g_launch_name;
+    if (e == 0) { e = (int)hipGetLastError(); *name = "(asynchronous error of an earlier call)"; }
+    g_launch_rc = 0; g_launch_name = nullptr;
+    return e;
+}
+static bool tg_launch_failed() { return g_launch_rc != 0; }
+static const char* tg_hip_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, tg_stream_t s) {
     return (int)hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, s);
 }
@@ -41,7 +61,6 @@ static int tg_memset(void* dst, int v, size_t n, tg_stream_t s) { return (int)hi
 static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t s) {
     return (int)hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
 }
-static int tg_check_launch() { return (int)hipGetLastError(); }
 typedef hipEvent_t tg_event_t;
 static int tg_stream_create(tg_stream_t* s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 static void tg_stream_destroy(tg_stream_t s) { if (s) (void)hipStreamDestroy(s); }
@@ -63,6 +82,14 @@ static int tg_fail(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* tg_last_error(void) { return g_err.c_str(); }
+// status of the launches issued since the last call: TG_OK, or TG_ERR_HIP naming the first kernel whose launch failed
+static int tg_launch_status() {
+    const char* name = nullptr;
+    const int e = tg_launch_error(&name);
+    if (e == 0) return TG_OK;
+    return tg_fail(TG_ERR_HIP, "launch of %s failed with HIP error %d (%s)", name ? name : "?", e, tg_hip_errstr(e));
+}
+#define TG_LAUNCH_CK() do { int _rc = tg_launch_status(); if (_rc) return _rc; } while (0)
 extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 
 static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
@@ -296,7 +323,7 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     const size_t n1 = (size_t)L.Cr * (L.Kp / PR::CH), n2 = (size_t)L.Kp * (L.Cp / PR::CH);
     TG_LAUNCH((tg_prep_sk<PR>), (n1 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return L.T == 256 ? tg_lds_attr<PR, TgGeoLarge>() : tg_lds_attr<PR, TgGeoSmall>();
 }
 
@@ -304,7 +331,7 @@ static int tg_softmax_stats_from_scratch(tg_mapper* m) {
     const TgLayout& L = m->L;
     float* M = (float*)(m->st + L.s_M);
     TG_LAUNCH(tg_row_stats, L.C, 1, 256, 64, m->stream, (const float*)M, L.C, L.V, L.Vp, m->fp(L.o_rowpair));
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -319,7 +346,7 @@ static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize,
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
     tg_prof_mark(m, "tg_merge_stats");
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -357,7 +384,7 @@ static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
         const int nrb = (L.V + TG_RB - 1) / TG_RB;
         TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_WG), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
         TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_wgn2));
-        TG_CK(tg_check_launch());
+        TG_LAUNCH_CK();
     }
     return TG_OK;
 }
@@ -428,7 +455,7 @@ static int tg_setup_autocorr(tg_mapper* m) {
     TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm));
     TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tm, (const float*)a.Tm, L.V, L.Kp, a.part);
     TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm) + 2 * (size_t)L.Kp);
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -542,7 +569,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rscale), (size_t)L.Cp, 3.0e38f);
-    if (tg_check_launch()) return bail(tg_fail(TG_ERR_HIP, "set-up kernel launch failed"));
+    if ((rc = tg_launch_status())) return bail(rc);
     if (cfg->mode == TG_MODE_CONSTRAINED) {
         if (tg_memcpy(m->st + L.s_F, in->F0_dev, (size_t)L.C * 4, m->stream)) return bail(tg_fail(TG_ERR_HIP, "copy of F0 failed"));
         if ((rc = tg_launch_filter(m, false, 0.f, nullptr))) return bail(rc);
@@ -802,6 +829,7 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
         // into the update (tg_adam_rowpass), which also leaves the regulariser row sums for tg_hist_regs / the filter
         tg_launch_bwd<PR>(m, m->stream, 0, m->L.nct, true);
         tg_prof_mark(m, "tg_bwd_kernel");
+        if (tg_launch_failed()) return tg_launch_status();       // stop at the first failed launch, named
         if ((rc = tg_launch_update(m, lr, !constrained, nullptr, 0, -1, true))) return rc;
         if (m->L.full) {
             tg_launch_hist_regs(m, m->stream, hist_row);
@@ -821,7 +849,7 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
         if ((rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false))) return rc;
     }
     m->step += 1;
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -858,7 +886,7 @@ static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool f
     if (prelaunch_next) tg_event_record(m->e_fwd, m->s_fwd);
     tg_stream_wait(m->stream, m->e_adam[L.bands - 1]);               // join: the caller's stream sees the updated state
     m->step += 1;
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -905,11 +933,17 @@ static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, con
             if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
             rc = tg_launch_rowdots<PR>(m, hist_row);
             break;
-        case 3:
+        case 3: {
+            const bool deferred = m->fin_pending;       // world = 1: the history row was left to the update kernel (tg_dghat_emit<SELF>)
             if ((rc = tg_launch_update(m, lr, false))) return rc;      // leaves the local (max, Z) pairs in TG_X_ROWPAIR
+            if (m->L.full && deferred) {                // ... so the regulariser scalars can only be added now (as tg_one_step does)
+                tg_launch_hist_regs(m, m->stream, hist_row);
+                tg_prof_mark(m, "tg_hist_regs");
+            }
             if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
             m->step += 1;
             break;
+        }
         case 4:
             if (!gathered || nranks < 1) return tg_fail(TG_ERR_INVALID, "phase 4 needs the gathered statistics");
             rc = tg_merge(m, gathered, nranks, true, false);
@@ -917,7 +951,7 @@ static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, con
         default: return tg_fail(TG_ERR_INVALID, "unknown phase %d", phase);
     }
     if (rc) return rc;
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -954,7 +988,7 @@ extern "C" int tg_mapper_result(tg_mapper* m, float* P_out_dev, float* F_out_dev
         if (m->cfg.mode != TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_INVALID, "F_out requested from an unconstrained mapper");
         TG_CK(tg_memcpy(F_out_dev, m->ws + L.o_fgate, (size_t)L.C * 4, m->stream));
     }
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -1009,7 +1043,7 @@ extern "C" int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t
         if ((rc = tg_launch_ghat_stats(m))) return rc;
         TG_CK(tg_memcpy2d(out_dev + k0, (size_t)ld_out * 4, m->ws + L.o_Ghat, (size_t)L.Kp * 4, (size_t)kc * 4, L.V, m->stream));
     }
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -1020,7 +1054,7 @@ extern "C" int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t*
                                                                                  (long long)n_rows, n_cols, col0, (long long)ld_out);
     TG_LAUNCH(tg_csr_cols_to_dense, n_rows, 1, 256, 0, (tg_stream_t)hip_stream, (const long long*)indptr_dev, (const int*)indices_dev, data_dev,
               col0, n_cols, out_dev, (long long)ld_out);
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 
@@ -1045,7 +1079,7 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     a.voxstat = m->fp(L.o_voxstat); a.nky = (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS; a.vnorm2 = m->fp(L.o_vnorm2); a.rowent = m->fp(L.o_rowent);
     a.out = out4_dev; a.K = L.K; a.Kp = L.Kp; a.V = L.V; a.Vr = L.Vr; a.C = L.C;
     TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);
-    TG_CK(tg_check_launch());
+    TG_LAUNCH_CK();
     return TG_OK;
 }
 

@@ -121,7 +121,9 @@ class HipMapperEngine:
         self.state = torch.empty(sizes.state_bytes, dtype=torch.uint8, device=self.device)
         self.workspace = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device=self.device)
         handle = ct.c_void_p()
-        self._hip_stream = self._stream()              # the stream every call of this handle is enqueued on
+        # the stream every call of this handle is enqueued on (the library binds to it at create())
+        self._torch_stream = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        self._hip_stream = self._stream()
         self._call(self._lib.tg_mapper_create, ct.byref(cfg), ct.byref(inp), self.state.data_ptr(),
                    self.workspace.data_ptr(), self._hip_stream, ct.byref(handle))
         self._h = handle
@@ -138,19 +140,40 @@ class HipMapperEngine:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-    def _call(self, fn, *args):
+    def _call(self, fn, *args, tensors=()):
         """One C-ABI call with this mapper's GPU as the current HIP device (the library enqueues on the stream it was created
-        with; HIP rejects a stream that does not belong to the current device)."""
-        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
-            with torch.cuda.device(self.device):
+        with; HIP rejects a stream that does not belong to the current device).
+
+        The caller may be on ANOTHER torch stream than the one the handle was created on (torch streams are non-blocking):
+        the creation stream first waits for the caller's stream (allocations / uploads issued there), and the caller's
+        stream waits for the library's work afterwards, so reads such as `.cpu()` see finished results.  `tensors`: buffers
+        allocated on the caller's stream that the library touches (kept from being recycled early by the caching allocator)."""
+        if self.device.type != "cuda":
+            return _capi.check(fn(*args))
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            foreign = cur != self._torch_stream
+            if foreign:
+                self._torch_stream.wait_stream(cur)
+                for t in tensors:
+                    if t is not None:
+                        t.record_stream(self._torch_stream)
+            try:
                 return _capi.check(fn(*args))
-        return _capi.check(fn(*args))
+            finally:
+                if foreign:
+                    cur.wait_stream(self._torch_stream)
 
     def close(self):
         if getattr(self, "_h", None):
             self._sync()
             self._lib.tg_mapper_destroy(self._h)
             self._h = None
+
+    def release(self):
+        """Destroy the handle and drop the state / workspace buffers (>= 16 bytes per cell x spot) right away."""
+        self.close()
+        self.state = self.workspace = self._keepalive = self._scratch_row = None
 
     def __del__(self):
         try:
@@ -164,12 +187,12 @@ class HipMapperEngine:
 
     def step(self, n_steps, lr, history=None, first_row=0):
         hp = history.data_ptr() if history is not None else None
-        self._call(self._lib.tg_mapper_step, self._h, int(n_steps), float(lr), hp, int(first_row))
+        self._call(self._lib.tg_mapper_step, self._h, int(n_steps), float(lr), hp, int(first_row), tensors=(history,))
 
     def phase(self, phase, lr=0.0, history_row=None, gathered=None, nranks=0):
         hp = history_row.data_ptr() if history_row is not None else None
         gp = gathered.data_ptr() if gathered is not None else None
-        self._call(self._lib.tg_mapper_phase, self._h, int(phase), float(lr), hp, gp, int(nranks))
+        self._call(self._lib.tg_mapper_phase, self._h, int(phase), float(lr), hp, gp, int(nranks), tensors=(history_row, gathered))
 
     def exchange_buffer(self, which):
         """A float32 torch view (no copy) of one of the cross-GPU exchange vectors inside the workspace."""
@@ -181,12 +204,12 @@ class HipMapperEngine:
     def result(self, with_filter=False):
         P = torch.empty((self.C, self.V), dtype=torch.float32, device=self.device)
         F = torch.empty((self.C,), dtype=torch.float32, device=self.device) if with_filter else None
-        self._call(self._lib.tg_mapper_result, self._h, P.data_ptr(), F.data_ptr() if with_filter else None)
+        self._call(self._lib.tg_mapper_result, self._h, P.data_ptr(), F.data_ptr() if with_filter else None, tensors=(P, F))
         return (P, F) if with_filter else P
 
     def project(self):
         Gh = torch.empty((self.V, self.K), dtype=torch.float32, device=self.device)
-        self._call(self._lib.tg_mapper_project, self._h, Gh.data_ptr())
+        self._call(self._lib.tg_mapper_project, self._h, Gh.data_ptr(), tensors=(Gh,))
         return Gh
 
     def project_genes(self, S_all, unfiltered=True):
@@ -205,13 +228,15 @@ class HipMapperEngine:
         n = int(S_all.shape[1])
         out = torch.empty((self.V, n), dtype=torch.float32, device=self.device)
         self._call(self._lib.tg_mapper_project_genes, self._h, S_all.data_ptr(), int(S_all.stride(0)), n, out.data_ptr(), n,
-                   1 if unfiltered else 0)
+                   1 if unfiltered else 0, tensors=(S_all, out))
         return out
 
     def _project_genes_csr(self, csr, unfiltered):
         if csr.shape[0] != self.C:
             raise ValueError("S_all must be [n_cells, n_genes] with the mapper's cells")
-        csr.sum_duplicates()                                         # canonical form: one entry per (row, column)
+        if not csr.has_canonical_format:                             # one entry per (row, column), on a COPY: `tocsr()` of a CSR
+            csr = csr.copy()                                         # matrix is the caller's own object (adata_sc.X must not change)
+            csr.sum_duplicates()
         n = int(csr.shape[1])
         indptr = torch.as_tensor(np.asarray(csr.indptr, dtype=np.int64), device=self.device)
         indices = torch.as_tensor(np.asarray(csr.indices, dtype=np.int32), device=self.device)
@@ -221,15 +246,15 @@ class HipMapperEngine:
         for k0 in range(0, n, self.K):
             kc = min(self.K, n - k0)
             self._call(self._lib.tg_csr_columns_to_dense, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), self.C, k0, kc,
-                       block.data_ptr(), int(block.stride(0)), self._hip_stream)
+                       block.data_ptr(), int(block.stride(0)), self._hip_stream, tensors=(indptr, indices, data, block))
             self._call(self._lib.tg_mapper_project_genes, self._h, block.data_ptr(), int(block.stride(0)), kc,
-                       out.data_ptr() + 4 * k0, n, 1 if unfiltered else 0)
+                       out.data_ptr() + 4 * k0, n, 1 if unfiltered else 0, tensors=(block, out))
         return out
 
     def validate(self):
         """(expression_sim, gv_sim, sparsity-weighted gv_sim, entropy) of the current mapping; one D2H copy."""
         out = torch.empty(4, dtype=torch.float32, device=self.device)
-        self._call(self._lib.tg_mapper_validate, self._h, out.data_ptr())
+        self._call(self._lib.tg_mapper_validate, self._h, out.data_ptr(), tensors=(out,))
         return [float(x) for x in out.cpu().numpy()]
 
     def logits(self):

@@ -131,7 +131,8 @@ class Mapper:
             out["total_loss"].append(np.array(row[_capi.H_TOTAL], dtype=np.float32))     # 0-d ndarray like :390
             out["main_loss"].append(float(row[_capi.H_MAIN]))
             out["vg_reg"].append(float(row[_capi.H_VG]) if self.lambda_g2 else nan)
-            out["kl_reg"].append(float(row[_capi.H_KL]) if self.target_density_enabled else nan)
+            # reference :219-220: kl_reg = (lambda_d * KL) / lambda_d -> nan when d is given but lambda_d == 0
+            out["kl_reg"].append(float(row[_capi.H_KL]) if (self.target_density_enabled and self.lambda_d) else nan)
             out["entropy_reg"].append(float(row[_capi.H_ENTROPY]) if self.lambda_r else nan)
         return out
 
@@ -167,6 +168,10 @@ class Mapper:
         return output, history
 
     # extras -----------------------------------------------------------------------------------------
+    def release(self):
+        """Free the device memory of this mapper (logits, Adam moments, X, workspace); the object is unusable afterwards."""
+        self._engine.release()
+
     def project_genes_device(self, S_all=None):
         """softmax(M)^T S on the device (what mapping_utils.py:402 and utils.py:368 compute in NumPy on the host);
         `S_all` [n_cells, n_genes_any]: project another gene set (project_genes), default: the training genes."""
@@ -247,12 +252,16 @@ class MapperConstrained:
         P, F = eng.result(with_filter=True)
         h = hist[:num_epochs].detach().cpu().numpy()
         cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_COUNT, _capi.H_FREG]
-        active = [True, True, bool(self.lambda_g2), self.target_density_enabled, bool(self.lambda_r), True, True]
+        active = [True, True, bool(self.lambda_g2), bool(self.target_density_enabled and self.lambda_d), bool(self.lambda_r), True, True]
         history = {k: [] for k in _KEYS_CONSTRAINED}
         for row in h:
             for k, c, on in zip(_KEYS_CONSTRAINED, cols, active):
                 history[k].append(str(float(row[c]) if on else float("nan")))
         return P.detach().cpu().numpy(), F.detach().cpu().numpy(), history
+
+    def release(self):
+        """Free the device memory of this mapper; the object is unusable afterwards."""
+        self._engine.release()
 
     def project_genes_device(self, S_all=None, unfiltered=True):
         """Like Mapper.project_genes_device; `unfiltered`: softmax(M) alone, as `adata_map.X` holds it (:637), else times

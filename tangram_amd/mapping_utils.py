@@ -98,8 +98,14 @@ def map_cells_to_space(
     density_prior="rna_count_based",
     *,
     gemm_precision="bf16x3",
+    keep_mapper=False,
 ):
-    """Map single cell data (`adata_sc`) on spatial data (`adata_sp`); see the reference docstring (:169-203)."""
+    """Map single cell data (`adata_sc`) on spatial data (`adata_sp`); see the reference docstring (:169-203).
+
+    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer); `keep_mapper=True` leaves the trained mapper on the
+    result as `adata_map._tangram_amd_mapper` so that `tangram_amd.project_genes(..., mapper=adata_map._tangram_amd_mapper)`
+    can project with the mapping still resident in HBM.  Default False: like the reference, the result owns no device
+    memory -- the logits, both Adam moments, X and the workspace (>= 16 bytes per cell x spot) are released before returning."""
     # ---- argument checks, reference :205-229
     if lambda_g1 == 0:
         raise ValueError("lambda_g1 cannot be 0.")
@@ -230,8 +236,8 @@ def map_cells_to_space(
     adata_map.uns["train_genes_df"]["sparsity_diff"] = (
         adata_sp[:, training_genes].var.sparsity - adata_sc[:, training_genes].var.sparsity)
     adata_map.uns["training_history"] = training_history                      # :426
-    try:        # keeps the trained mapping resident for tangram_amd.project_genes (not part of the AnnData contract)
+    if keep_mapper:     # opt-in: the trained mapping stays resident in HBM (not part of the AnnData contract)
         object.__setattr__(adata_map, "_tangram_amd_mapper", mapper)
-    except Exception:
-        pass
+    else:
+        mapper.release()
     return adata_map

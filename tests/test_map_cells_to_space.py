@@ -148,18 +148,29 @@ def test_project_genes_on_device(sim):
     ad_sc.X = ad_sc.X.copy(); ad_sc.X[:, -1] = 0                           # an all-zero gene is dropped (:357)
     ad_sc_train = AnnDataLite(ad_sc.X, obs=ad_sc.obs, var=pd.DataFrame(index=[g.lower() for g in ad_sc.var.index]), uns=ad_sc.uns)
     ad_map = tg.map_cells_to_space(ad_sc_train, ad_sp, mode="cells", device="cpu", num_epochs=3, random_state=42,
-                                   verbose=False, gemm_precision="fp32")
-    ad_ge = tg.project_genes(ad_map, ad_sc, device="cpu", gemm_precision="fp32")
+                                   verbose=False, gemm_precision="fp32", keep_mapper=True)
+    # explicit `mapper=`: the projection uses the mapping that is still resident on the device
+    ad_ge = tg.project_genes(ad_map, ad_sc, device="cpu", gemm_precision="fp32", mapper=ad_map._tangram_amd_mapper)
     keep = [g.lower() for g in ad_sc.var.index]
     assert ad_ge.X.shape == (25, 18) and list(ad_ge.var.index) == keep[:18]
     assert list(ad_ge.obs.index) == list(ad_sp.obs.index)
     assert ad_ge.var["is_training"].sum() == 12 and "n_cells" in ad_ge.var.columns
     want = ad_map.X.astype(np.float64).T @ ad_sc_train.X[:, :18].astype(np.float64)
     np.testing.assert_allclose(ad_ge.X, want, rtol=1e-5, atol=1e-6)
-    # without the live mapper (an adata_map restored from disk): the mapping matrix is uploaded once
-    object.__delattr__(ad_map, "_tangram_amd_mapper")
+    # default (reference semantics, utils.py:366): the mapping matrix the caller passes, `adata_map.X`, is what gets projected,
+    # even with a live mapper on the object -- an edited adata_map.X must not be silently replaced by the trained mapping
     ad_ge2 = tg.project_genes(ad_map, ad_sc, device="cpu", gemm_precision="fp32")
     np.testing.assert_allclose(ad_ge2.X, want, rtol=2e-5, atol=2e-6)
+    X_saved = ad_map.X.copy()
+    ad_map.X = ad_map.X[:, ::-1] * np.linspace(0.2, 1.5, ad_map.X.shape[0], dtype=np.float32)[:, None]   # edited: not even row-stochastic
+    ad_ge3 = tg.project_genes(ad_map, ad_sc, device="cpu", gemm_precision="fp32")
+    np.testing.assert_allclose(ad_ge3.X, ad_map.X.astype(np.float64).T @ ad_sc_train.X[:, :18].astype(np.float64), rtol=2e-5, atol=2e-6)
+    ad_map.X = X_saved
+    ad_map._tangram_amd_mapper.release()
+    # by default the result owns no device memory (no mapper attached)
+    ad_map_plain = tg.map_cells_to_space(ad_sc_train, ad_sp, mode="cells", device="cpu", num_epochs=1, random_state=42,
+                                         verbose=False, gemm_precision="fp32")
+    assert not hasattr(ad_map_plain, "_tangram_amd_mapper")
     # clusters: the single-cell matrix is aggregated the same way as for the mapping (:359-360)
     ad_map_c = tg.map_cells_to_space(ad_sc_train, ad_sp, mode="clusters", cluster_label="subclass_label", device="cpu",
                                      num_epochs=3, random_state=42, verbose=False, gemm_precision="fp32")
