@@ -1,17 +1,25 @@
 #!/usr/bin/env python
 """Benchmark of the Tangram mapping hot path on MI355X (BASELINE.json metric: mapping iterations/s and
-cell*spot*gene/s at 30k cells x 1k genes x 10k spots).
+cell*spot*gene/s at 30k cells x 1k genes x 10k spots; the other BASELINE configurations are --workload choices).
 
-    python bench.py --gpus N --steps K --warmup W [--precision bf16x3|bf16|fp32]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg4|cfg5a|cfg5b] [--precision bf16x3|bf16|fp32]
 
 One "step" = one full mapping iteration (softmax, P^T S, cosine + density loss, backward, Adam) on synthetic
-inputs of the named shape that are resident in HBM before the timed region starts.  N > 1 is launched by
-torch.distributed.run (one rank per GPU, RCCL): the spots are sharded over the ranks (strong scaling: the
-problem is fixed, `value` is whole-job iterations/s).  Rank 0 prints ONE JSON line.
+inputs of the named shape that are resident in HBM before the timed region starts.
+
+  cfg2   30 000 cells x 1 000 genes x 10 000 spots, mode='cells' defaults (lambda_g1 = lambda_d = 1)      -- the headline
+  cfg4   200 000 x 2 000 x 50 000, bf16 MFMA operands, fp32 accumulate / state (fits ONE 288 GB GPU; sharded for N > 1)
+  cfg5a  cfg2 shape, mode='constrained' (MapperConstrained: density + count + f_reg terms, target_count = V)
+  cfg5b  cfg2 shape, mode='cells' + lambda_neighborhood_g1 = 0.96 + lambda_ct_islands = 0.17 on a 6-neighbour hex spot graph
+
+N > 1: `python bench.py --gpus N` re-executes itself through torch.distributed.run (one rank per GPU, RCCL); the spots are
+sharded over the ranks (strong scaling: the problem is fixed, `value` is whole-job iterations/s).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,16 +27,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK = 8.0e12                      # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
+HBM_PEAK = 8.0e12                      # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec; 6.29 TB/s measured float4 copy)
+HBM_COPY = 6.29e12
 # dense matrix-core peak for ONE algorithmic product: bf16 2.5 PFLOP/s; split-bf16 x3 issues three bf16 MFMAs per product, i.e.
 # 833 TFLOP/s effective (the figure SURVEY 8(d) prices the bf16x3 roofline with); exact f32 MFMA 157.3 TFLOP/s
 MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15 / 3.0, "fp32": 157.3e12}
 DTYPE_NAME = {"bf16x3": "f32 (split-bf16 x3 MFMA operands, f32 accumulate and state: fp32-parity)",
               "bf16": "bf16 MFMA operands, f32 accumulate and state", "fp32": "f32 (exact f32 MFMA)"}
-WORKLOADS = {"cfg2": (30000, 1000, 10000)}
+WORKLOADS = {
+    # name: (C, K, V, mode, default GEMM precision, description)
+    "cfg2": (30000, 1000, 10000, "cells", "bf16x3", "mode='cells', lambda_g1=1, lambda_d=1"),
+    "cfg4": (200000, 2000, 50000, "cells", "bf16", "mode='cells', lambda_g1=1, lambda_d=1, bf16 operands / fp32 state"),
+    "cfg5a": (30000, 1000, 10000, "constrained", "bf16x3", "mode='constrained', lambda_d=lambda_g1=lambda_count=lambda_f_reg=1, target_count=V"),
+    "cfg5b": (30000, 1000, 10000, "spatial", "bf16x3", "mode='cells', lambda_g1=lambda_d=1, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17, "
+                                                     "18 cell types, 6-neighbour hex spot graph (CSR)"),
+}
+HEAVY = ("tg_fwd_kernel", "tg_bwd_kernel", "tg_adam_rowpass", "tg_adam_update")
 
 
 def kernel_model(name, C, K, V):
@@ -44,63 +58,153 @@ def kernel_model(name, C, K, V):
     return None, None
 
 
-def pmc_traffic(kernel, precision):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE), or None."""
+def pmc_traffic(precision):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE); {} when not collected."""
     try:
         tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return tab[precision][kernel]["hbm_bytes_per_launch"]
+        return {k: v["hbm_bytes_per_launch"] for k, v in tab[precision].items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
     except Exception:
-        return None
+        return {}
 
 
-def cpu_baseline(C, K, V, seed=0):
-    """The reference's CPU path (PyTorch port in oracle/torch_port.py, same op sequence) on a bounded sample."""
-    from oracle.torch_port import TorchPortMapper
-    from tangram_amd.synthetic import make_workload
-    Cs, Vs = max(C // 5, 64), max(V // 5, 64)              # 1/25 of the C*V plane, all K genes
-    torch.set_num_threads(os.cpu_count() or 1)
-    w = make_workload(Cs, K, Vs, "cpu", seed=seed)
-    m = TorchPortMapper(w["S"].numpy(), w["G"].numpy(), d=w["d"].numpy(), lambda_g1=1, lambda_d=1, random_state=42)
+def roof_of(bytes_alg, flops_alg, seconds, precision, traffic=None):
+    """Roofline entry for `seconds` of work with the given algorithmic bytes / flops: the BINDING roof is the larger of
+    t_HBM = bytes / 8 TB/s and t_MFMA = flops / dense peak of the precision; frac = that time / measured time."""
+    t_h = bytes_alg / HBM_PEAK
+    t_m = flops_alg / MFMA_PEAK[precision]
+    if t_h >= t_m:
+        return {"bound": "hbm", "achieved": bytes_alg / seconds / 1e12, "peak": HBM_PEAK / 1e12, "unit": "TB/s",
+                "frac": t_h / seconds, "traffic": traffic}
+    return {"bound": "mfma", "achieved": flops_alg / seconds / 1e12, "peak": MFMA_PEAK[precision] / 1e12, "unit": "TFLOP/s",
+            "frac": t_m / seconds, "traffic": traffic}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(workload, C, K, V):
+    """The reference's CPU path on the GPU box's host cores: oracle/torch_port.py (PyTorch-CPU port with the reference's op
+    sequence; the unmodified reference lives in /root/reference, which does not exist here) on a bounded sample.
+    Thread count: swept on a small probe first (256 threads on element-wise ops across two sockets is oversubscription,
+    VERDICT r01), then 1 warm-up + 2 timed iterations on 1/4 of the cell x spot plane with all K genes."""
+    import torch
+    from oracle.torch_port import TorchPortMapper, TorchPortMapperConstrained
+    from tangram_amd.synthetic import make_workload, hex_grid_graph, cell_type_encoding
+    ncpu = os.cpu_count() or 1
+
+    def build(Cs, Vs):
+        w = make_workload(Cs, K, Vs, "cpu", seed=0)
+        S, G, d = w["S"].numpy(), w["G"].numpy(), w["d"].numpy()
+        if workload == "cfg5a":
+            return TorchPortMapperConstrained(S, G, d, lambda_d=1, lambda_g1=1, lambda_g2=0, lambda_count=1, lambda_f_reg=1,
+                                              target_count=Vs, random_state=42)
+        if workload == "cfg5b":           # the reference takes DENSE V x V weight matrices (mapping_optimizer.py:125-132)
+            N, W = hex_grid_graph(Vs)
+            E = cell_type_encoding(w["assign"].numpy(), Vs, 18)
+            return TorchPortMapper(S, G, d=d, lambda_g1=1, lambda_d=1, lambda_neighborhood_g1=0.96, voxel_weights=W.toarray(),
+                                   lambda_ct_islands=0.17, neighborhood_filter=N.toarray(), ct_encode=E, random_state=42)
+        return TorchPortMapper(S, G, d=d, lambda_g1=1, lambda_d=1, random_state=42)
+
+    def time_iters(m, n):
+        t0 = time.perf_counter()
+        m.train(n, 0.1)
+        return (time.perf_counter() - t0) / n
+
+    t_begin = time.perf_counter()
+    # probe: 1/64 of the plane, one timed iteration per thread count
+    Cp, Vp = max(C // 8, 64), max(V // 8, 64)
+    probe = build(Cp, Vp)
+    torch.set_num_threads(min(32, ncpu))
+    probe.train(1, 0.1)
+    sweep = {}
+    for nt in [n for n in (8, 16, 32, 64, 128, 256) if n <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        sweep[nt] = min(time_iters(probe, 1), time_iters(probe, 1))
+    best = min(sweep, key=sweep.get)
+    del probe
+    torch.set_num_threads(best)
+    Cs, Vs = max(C // 2, 64), max(V // 2, 64)              # 1/4 of the C*V plane, all K genes
+    m = build(Cs, Vs)
     m.train(1, 0.1)                                        # warm-up (cold first iteration)
-    n = 3
-    t0 = time.perf_counter()
-    m.train(n, 0.1)
-    dt = (time.perf_counter() - t0) / n
+    n = 2
+    dt = time_iters(m, n)
     csg = Cs * K * Vs / dt
+    ratio = None
+    try:
+        ratio = json.load(open(os.path.join(ROOT, "oracle", "port_vs_reference.json")))["port_over_reference_time"]
+    except Exception:
+        pass
     return {"value": csg / (float(C) * K * V), "unit": "iters/s (cell*spot*gene/s of the sample / C*K*V of the workload)",
-            "cell_spot_gene_per_s": csg, "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} iterations of oracle/torch_port.py (PyTorch-CPU port of the reference loop, fp32) at "
-                      f"{Cs}x{K}x{Vs} = 1/25 of the cell x spot plane, {dt:.2f} s/iter"}
+            "cell_spot_gene_per_s": csg, "cores": best, "kind": "port",
+            "sample": f"{n} iterations (after 1 warm-up) of oracle/torch_port.py (PyTorch-CPU port of the reference loop, fp32) at "
+                      f"{Cs}x{K}x{Vs} = 1/4 of the cell x spot plane, {dt:.2f} s/iter, {best} threads "
+                      f"(best of a sweep on a {Cp}x{K}x{Vp} probe: " + ", ".join(f"{k}: {v:.3f} s" for k, v in sweep.items()) + ")",
+            "host_cpus": ncpu, "thread_sweep_s_per_iter": {str(k): v for k, v in sweep.items()},
+            "port_over_reference_time": ratio,
+            "port_over_reference_note": "wall time of this port / the UNMODIFIED reference Mapper on the same inputs and threads, "
+                                        "measured once in the authoring container (oracle/measure_port_ratio.py)",
+            "wall_s": time.perf_counter() - t_begin}
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
-    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--steps", type=int, default=200)         # SURVEY 8(d): >= 200 timed iterations after >= 20 warm-up
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "bf16", "fp32"], help="GEMM precision (default: the workload's)")
     ap.add_argument("--shape", default=None, help="override C,K,V (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short runs of the other GEMM precisions")
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile edge (128 or 256); 0 = automatic")
     ap.add_argument("--bands", type=int, default=0, help="cell bands of the opt-in 3-stream pipeline (0/1 = sequential schedule, the default)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def respawn_distributed(args):
+    """`python bench.py --gpus N` without a launcher: re-execute through torch.distributed.run, one rank per GPU."""
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    backend = os.environ.get("TG_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {ndev} "
+              f"(RCCL cannot share a device between ranks)", file=sys.stderr)
+        sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn_distributed(args)
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
+        print("bench.py needs a HIP device (there is no CPU path)", file=sys.stderr)
+        sys.exit(2)
     ndev = torch.cuda.device_count()
     backend = os.environ.get("TG_BENCH_BACKEND", "nccl")       # "gloo": plumbing smoke test of the N > 1 path on a 1-GPU box
     if world > 1 and backend == "nccl" and world > ndev:
-        raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev}); RCCL cannot share a device between ranks")
+        print(f"bench.py: {world} ranks need {world} GPUs (found {ndev}); RCCL cannot share a device between ranks", file=sys.stderr)
+        sys.exit(2)
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -113,27 +217,46 @@ def main():
 
     from tangram_amd.engine import HipMapperEngine
     from tangram_amd.sharded import ShardedMapperEngine, shard_bounds
-    from tangram_amd.synthetic import make_workload, init_logits
+    from tangram_amd.synthetic import make_workload, init_logits, hex_grid_graph, cell_type_encoding
 
-    C, K, V = WORKLOADS[args.workload] if not args.shape else tuple(int(x) for x in args.shape.split(","))
-    lam = dict(lambda_g1=1.0, lambda_d=1.0)        # mode='cells' defaults as resolved by mapping_utils.py:214-215
+    C, K, V, mode, default_prec, wl_desc = WORKLOADS[args.workload]
+    if args.shape:
+        C, K, V = (int(x) for x in args.shape.split(","))
+    precision = args.precision or default_prec
+    if world > 1 and mode == "spatial":
+        print("bench.py: the spatial terms need the whole spot graph on one GPU (cfg5b is a 1-GPU configuration)", file=sys.stderr)
+        sys.exit(2)
     w = make_workload(C, K, V, device, seed=0)
     lr = 0.1
-    if world == 1:
-        M0 = init_logits(C, V, device, seed=42)
-        eng = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=args.precision, lambdas=lam,
-                              fwd_splits=args.splits, tile_size=args.tile, pipeline_bands=args.bands)
-        del M0
-        run = lambda n: eng.step(n, lr)
-        core = eng
+    extra = {}
+    if mode == "constrained":
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.0, lambda_count=1.0, lambda_f_reg=1.0)
+        extra = dict(mode="constrained", target_count=float(V))
+    elif mode == "spatial":
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17)   # values of README.md:96-100
+        N, W = hex_grid_graph(V)
+        extra = dict(voxel_weights=W, neighborhood_filter=N, ct_encode=cell_type_encoding(w["assign"].cpu().numpy(), V, 18))
     else:
+        lam = dict(lambda_g1=1.0, lambda_d=1.0)        # mode='cells' defaults as resolved by mapping_utils.py:214-215
+
+    def make_engine(prec):
+        if world == 1:
+            M0 = init_logits(C, V, device, seed=42)
+            if mode == "constrained":
+                extra["F0"] = torch.randn(C, device=device, generator=torch.Generator(device=device).manual_seed(7))
+            e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=prec, lambdas=lam,
+                                fwd_splits=args.splits, tile_size=args.tile, pipeline_bands=args.bands, **extra)
+            return e, e, (lambda n, h=None: e.step(n, lr, h))
         lo, hi = shard_bounds(V, world, rank)
         M0 = init_logits(C, hi - lo, device, seed=42 + rank)
+        kw = dict(extra)
+        if mode == "constrained":
+            kw["F0"] = torch.randn(C, device=device, generator=torch.Generator(device=device).manual_seed(7))
         sh = ShardedMapperEngine(w["S"], w["G"][lo:hi].contiguous(), M0, w["d"][lo:hi].contiguous(), n_spots_total=V,
-                                 device=device, precision=args.precision, lambdas=lam, fwd_splits=args.splits, tile_size=args.tile)
-        del M0
-        run = lambda n: sh.run(n, lr)
-        core = sh.eng
+                                 device=device, precision=prec, lambdas=lam, fwd_splits=args.splits, tile_size=args.tile, **kw)
+        return sh, sh.eng, (lambda n, h=None: sh.run(n, lr, h))
+
+    owner, core, run = make_engine(precision)
     torch.cuda.empty_cache()
 
     def fence():
@@ -163,32 +286,31 @@ def main():
 
     # sanity: the loss of the last step is finite (nothing was skipped)
     hist = core.new_history(1)
-    if world == 1:
-        eng.step(1, lr, hist)
-    else:
-        sh.run(1, lr, hist)
+    run(1, hist)
     torch.cuda.synchronize(device)
     main_loss = float(hist[0, 1].item())
+    if not (main_loss == main_loss):
+        print("bench.py: the last step's main_loss is NaN", file=sys.stderr)
+        sys.exit(3)
 
     # the other GEMM precisions on the same inputs (reported beside the headline, never as `value`)
     alt = {}
-    if world == 1 and not args.no_alt:
-        del eng, core
+    if world == 1 and not args.no_alt and args.workload != "cfg4":
+        owner.release() if hasattr(owner, "release") else None
+        del owner, core, run
         torch.cuda.empty_cache()
-        for prec in [p for p in ("bf16x3", "bf16", "fp32") if p != args.precision]:
-            M0 = init_logits(C, V, device, seed=42)
-            e2 = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=prec, lambdas=lam)
-            del M0
-            n2 = max(4, args.steps // 4)
-            e2.step(2, lr)
+        for prec in [p for p in ("bf16x3", "bf16", "fp32") if p != precision]:
+            e2, _, run2 = make_engine(prec)
+            n2 = max(4, min(args.steps // 4, 50))
+            run2(3)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
-            e2.step(n2, lr)
+            run2(n2)
             torch.cuda.synchronize(device)
             dt = (time.perf_counter() - t1) / n2
             alt[prec] = {"value": 1.0 / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt, "steps": n2, "dtype": DTYPE_NAME[prec]}
-            e2.close()
-            del e2
+            e2.release()
+            del e2, run2
             torch.cuda.empty_cache()
     del w
 
@@ -196,52 +318,59 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         its = args.steps / elapsed
         Vl = V if world == 1 else (shard_bounds(V, world, 0)[1])
+        # the committed PMC table was collected on the full single-GPU cfg2 launch: it does not describe a shard or another shape
+        pmc = pmc_traffic(precision) if (world == 1 and not args.shape and args.workload == "cfg2") else {}
         kern = []
         for name, ms, cnt in prof:
             b, f = kernel_model(name, C, K, Vl)
-            kern.append({"name": name, "avg_ms": ms / max(cnt, 1), "launches": cnt,
-                         "alg_GB": None if b is None else b / 1e9, "alg_GFLOP": None if f is None else f / 1e9})
-        dom = max((k for k in kern if k["alg_GB"] is not None), key=lambda k: k["avg_ms"] * k["launches"], default=None)
-        roof = None
-        # the committed PMC table was collected on the full single-GPU cfg2 launch: it does not describe a shard or another shape
-        traffic_of = (lambda k: pmc_traffic(k, args.precision)) if (world == 1 and not args.shape) else (lambda k: None)
-        if dom is not None:
-            t = dom["avg_ms"] * 1e-3
-            t_h = dom["alg_GB"] * 1e9 / HBM_PEAK
-            t_m = dom["alg_GFLOP"] * 1e9 / MFMA_PEAK[args.precision]
-            if t_h >= t_m:
-                roof = {"kernel": dom["name"], "bound": "hbm", "achieved": dom["alg_GB"] / t / 1e3, "peak": HBM_PEAK / 1e12,
-                        "unit": "TB/s", "frac": (dom["alg_GB"] * 1e9 / t) / HBM_PEAK, "traffic": traffic_of(dom["name"])}
-            else:
-                roof = {"kernel": dom["name"], "bound": "mfma", "achieved": dom["alg_GFLOP"] / t / 1e3,
-                        "peak": MFMA_PEAK[args.precision] / 1e12, "unit": "TFLOP/s",
-                        "frac": (dom["alg_GFLOP"] * 1e9 / t) / MFMA_PEAK[args.precision], "traffic": traffic_of(dom["name"])}
-        bytes_alg = 24.0 * C * V + 8.0 * (C * K + V * K)          # SURVEY 8(d), whole iteration, all GPUs
+            row = {"name": name, "avg_ms": ms / max(cnt, 1), "launches": cnt,
+                   "alg_GB": None if b is None else b / 1e9, "alg_GFLOP": None if f is None else f / 1e9}
+            if b is not None and cnt:
+                row["roofline"] = roof_of(b, f, 1e-3 * ms / cnt, precision, pmc.get(name))
+            kern.append(row)
+        # The roofline of the ITERATION: bytes_alg = 24 C V + 8 (C K + V K), flops_alg = 4 C V K over all GPUs; the
+        # binding roof is the larger of t_HBM and t_MFMA, frac = that time / measured time per step.  The heavy kernels follow
+        # with their own figures (kernel durations: HIP events on the kernel's stream, averaged over the profiled steps).
+        bytes_alg = 24.0 * C * V + 8.0 * (C * K + V * K)
         flops_alg = 4.0 * C * V * K
+        it_traffic = sum(pmc.get(k["name"], 0.0) for k in kern if k["name"] in HEAVY) if pmc else None
+        roof = roof_of(bytes_alg / world, flops_alg / world, elapsed / args.steps, precision, it_traffic or None)
+        roof["scope"] = "one iteration (all kernels of a step, per GPU)"
+        roof["bytes_alg"] = bytes_alg
+        roof["flops_alg"] = flops_alg
+        roof["hbm_frac"] = bytes_alg * its / HBM_PEAK / world
+        roof["hbm_frac_of_measured_copy_bw"] = bytes_alg * its / HBM_COPY / world
+        roof["mfma_frac"] = flops_alg * its / MFMA_PEAK[precision] / world
+        roof["kernels"] = [dict(name=k["name"], avg_ms=k["avg_ms"], **k["roofline"]) for k in kern if "roofline" in k]
+        metric = ("mapping iterations/s at 30k cells x 1k genes x 10k spots (mode='cells', lambda_g1=1, lambda_d=1)"
+                  if args.workload == "cfg2" and not args.shape else
+                  f"mapping iterations/s at {C} cells x {K} genes x {V} spots ({wl_desc})")
         out = {
-            "metric": "mapping iterations/s at 30k cells x 1k genes x 10k spots (mode='cells', lambda_g1=1, lambda_d=1)",
+            "metric": metric,
             "value": its, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {C} cells x {K} genes x {V} spots, planted-mapping synthetic "
-                                   f"counts, Adam lr=0.1", "gemm_precision": args.precision,
+            "dtype": DTYPE_NAME[precision], "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {C} cells x {K} genes x {V} spots, {wl_desc}; planted-mapping synthetic "
+                                   f"counts, Adam lr=0.1", "gemm_precision": precision,
                        "parallelism": "single GPU" if world == 1 else f"spots sharded over {world} GPUs, 3 small RCCL exchanges/step"},
             "cell_spot_gene_per_s": its * C * K * V,
             "last_main_loss": main_loss,
             "roofline": roof,
-            "iteration_roofline": {"bytes_alg": bytes_alg, "flops_alg": flops_alg,
-                                   "hbm_frac": bytes_alg * its / HBM_PEAK / world,
-                                   "mfma_frac": flops_alg * its / MFMA_PEAK[args.precision] / world},
             "kernels": kern,
             "kernels_pass": {"schedule": "sequential (one stream, HIP event after every kernel)", "steps": nprof,
                              "ms_per_step": 1e3 * seq_elapsed / nprof, "value": nprof / seq_elapsed},
             "alt_precisions": alt,
         }
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(C, K, V)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"error": repr(e)}
+            if args.workload == "cfg4":
+                out["cpu_baseline"] = {"value": None, "kind": "port", "cores": 0, "unit": "iters/s",
+                                       "sample": "not runnable on the CPU reference: M alone is 40 GB fp32 plus ~9x that in autograd "
+                                                 "temporaries (BASELINE.md section 3, item 5); see the cfg2 line for the CPU rate per cell*spot*gene"}
+            else:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(args.workload, C, K, V)
+                except Exception as e:  # the baseline must never take the GPU number down with it
+                    out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

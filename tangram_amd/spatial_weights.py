@@ -11,13 +11,28 @@ def spatial_weights(adata_sp, standardized, self_inclusion):
         raise ValueError("Missing spatial neighborhood parameters. Run `pp_adatas()` with the spatial information "
                          "stored in `spatial` in `adata_sp.obsm`.")                      # reference :11-12
     if standardized:
-        # reference :14-24: neighbours from the connectivity pattern, weights = row-L1-normalised distances
+        # reference :14-24: for every spot, `neighbors` = the columns where the connectivity row is non-zero and
+        # `neighbor_weights` = the non-zero values of the row-L1-normalised distance row, both in ascending column order;
+        # libpysal.weights.W(neighbors, neighbor_weights).sparse then pairs them POSITIONALLY (j-th neighbour <- j-th weight,
+        # the shorter list wins).  With squidpy's output the two patterns coincide and this is simply the normalised distance
+        # at the connectivity positions; the positional pairing is reproduced for inputs where they do not.
+        # (The reference also normalises adata_sp.obsp['spatial_distances'] IN PLACE, `copy=False` at :16 -- not reproduced.)
         conn = sp.csr_matrix(adata_sp.obsp["spatial_connectivities"]).astype(np.float32)
-        dist = sp.csr_matrix(adata_sp.obsp["spatial_distances"]).astype(np.float32)
+        dist = sp.csr_matrix(adata_sp.obsp["spatial_distances"]).astype(np.float64)
+        conn.sum_duplicates(); conn.eliminate_zeros(); conn.sort_indices()
+        dist.sum_duplicates(); dist.sort_indices()
         rs = np.asarray(np.abs(dist).sum(axis=1)).reshape(-1)
         rs[rs == 0] = 1.0
-        w = sp.diags(1.0 / rs) @ dist
-        w = w.multiply(conn != 0).tocsr()              # keep the connectivity pattern
+        dist = (sp.diags(1.0 / rs) @ dist).tocsr()
+        dist.eliminate_zeros(); dist.sort_indices()
+        n = conn.shape[0]
+        nc, nd = np.diff(conn.indptr), np.diff(dist.indptr)
+        take = np.minimum(nc, nd)                                   # zip() stops at the shorter list
+        rows = np.repeat(np.arange(n), take)
+        within = np.arange(take.sum()) - np.repeat(np.cumsum(take) - take, take)
+        cols = conn.indices[np.repeat(conn.indptr[:-1], take) + within]
+        vals = dist.data[np.repeat(dist.indptr[:-1], take) + within]
+        w = sp.csr_matrix((vals.astype(np.float32), (rows, cols)), shape=conn.shape)
     else:
         w = sp.csr_matrix(adata_sp.obsp["spatial_connectivities"]).astype(np.float32)    # reference :26
     if self_inclusion:

@@ -39,3 +39,41 @@ def init_logits(C, V, device, seed=42):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     return torch.randn((C, V), dtype=torch.float32, device=device, generator=g)
+
+
+def hex_grid_graph(V):
+    """Synthetic spot graph of BASELINE config 5b: V spots on a 2-D hexagonal grid (odd rows shifted by half a
+    spot), 6 neighbours inside the grid -- what `sq.gr.spatial_neighbors` yields for Visium spots.  Returns scipy CSR
+    (N, W): N = binary adjacency without self loops (`neighborhood_filter`, mapping_utils.py:324), W = row-normalised
+    weights + identity (`voxel_weights`, mapping_utils.py:320; spatial_weights.py:14-28 with unit distances)."""
+    import numpy as np
+    import scipy.sparse as sp
+    w = int(np.ceil(np.sqrt(V)))
+    idx = np.arange(V)
+    r, c = idx // w, idx % w
+    rows, cols = [], []
+    for dr, dc_even, dc_odd in ((0, -1, -1), (0, 1, 1), (-1, -1, 0), (-1, 0, 1), (1, -1, 0), (1, 0, 1)):
+        rr = r + dr
+        cc = c + np.where(r % 2 == 0, dc_even, dc_odd)
+        j = rr * w + cc
+        ok = (rr >= 0) & (cc >= 0) & (cc < w) & (j >= 0) & (j < V)
+        rows.append(idx[ok])
+        cols.append(j[ok])
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    N = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(V, V))
+    N.sum_duplicates()
+    N.data[:] = 1.0
+    rs = np.asarray(N.sum(axis=1)).reshape(-1)
+    rs[rs == 0] = 1.0
+    W = (sp.diags((1.0 / rs).astype(np.float32)) @ N + sp.identity(V, dtype=np.float32, format="csr")).tocsr()
+    return N, W
+
+
+def cell_type_encoding(assign, V, n_types):
+    """One-hot cell types for config 5b: the type of a cell is the region label of its planted spot."""
+    import numpy as np
+    assign = np.asarray(assign)
+    lab = (assign.astype(np.int64) * n_types) // V
+    E = np.zeros((len(assign), n_types), np.float32)
+    E[np.arange(len(assign)), lab] = 1.0
+    return E

@@ -1,0 +1,181 @@
+"""GPU parity at PRODUCTION tile counts (-m gpu), closing the size hole of the golden fixtures (<= 300 x 60 x 120):
+
+ (i)  4 200 x 1 000 x 1 500 against the fp64 NumPy oracle: K = 1 000 => 4 gene tiles of 256 and 32 contraction steps in the
+      backward GEMM, 17 cell tiles x 6 spot tiles, several forward splits -- both tile geometries, all three GEMM precisions,
+      5 epochs of trajectory + the first-step gradient (recovered from Adam's first moment);
+ (ii) the full BASELINE shape 30 000 x 1 000 x 10 000 against the REFERENCE'S OWN OP SEQUENCE (oracle/torch_port.py: softmax,
+      matmul, cosine_similarity, KLDivLoss, autograd, torch.optim.Adam -- what the reference executes with device='cuda')
+      run by PyTorch-ROCm in fp32 on the same GPU: first-step gradient and a 3-step loss trajectory, cells and constrained.
+
+The checker is the oracle; the thing under test is the C-ABI library.  Tolerances: the stated fp32 tolerances of
+tests/parity_common.py (loss 1e-5, gradient rel 1e-5 vs fp64 / 1e-4 vs the fp32 torch run, whose own round-off is ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BETA1 = 0.9
+
+C1, K1, V1, N1 = 4200, 1000, 1500, 5
+
+
+@pytest.fixture(scope="module")
+def oracle_k1000():
+    """fp64 oracle run shared by every parametrisation below (about 10 s of host time)."""
+    from oracle import tangram_oracle as orc
+    data = orc.make_synthetic(C1, K1, V1, seed=21)
+    M0 = orc.reference_init_M(C1, V1, 5)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    _, dM = o.loss_and_grad()
+    Po, ho = o.train(N1, 0.1)
+    Gh = Po.T @ data["S"].astype(np.float64)
+    return dict(data=data, M0=M0, lam=lam, dM=dM, P=Po, hist=ho, Ghat=Gh)
+
+
+@pytest.mark.parametrize("tile", [256, 128])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
+def test_k1000_multi_tile_against_oracle_fp64(oracle_k1000, precision, tile):
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    o = oracle_k1000
+    data = o["data"]
+    e = HipMapperEngine(data["S"], data["G"], o["M0"], d=data["d"], device=DEV, precision=precision, lambdas=o["lam"],
+                        tile_size=tile)
+    hist = e.new_history(N1)
+    e.step(1, 0.1, hist, 0)
+    _, m1, _, _ = e.logits()
+    g = (m1[:, :V1] / (1.0 - BETA1)).cpu().numpy().astype(np.float64)        # exp_avg after one step = (1 - beta1) * grad
+    rel = np.linalg.norm(g - o["dM"]) / np.linalg.norm(o["dM"])
+    assert rel <= (1e-5 if precision != "bf16" else 1e-2), f"first-step gradient rel err {rel:.3e}"
+    e.step(N1 - 1, 0.1, hist, 1)
+    h = hist.cpu().numpy().astype(np.float64)
+    tol = pc.TOL[precision]
+    for k, col in (("total_loss", _capi.H_TOTAL), ("main_loss", _capi.H_MAIN), ("vg_reg", _capi.H_VG), ("kl_reg", _capi.H_KL)):
+        err = float(np.abs(h[:, col] - np.asarray(o["hist"][k], dtype=np.float64)).max())
+        assert err <= tol["loss"], f"{k}: max per-epoch |delta| {err:.3e}"
+    P = e.result().cpu().numpy()
+    assert float(np.abs(P - o["P"]).max()) <= tol["P"]
+    Gh = e.project().cpu().numpy()
+    relg = np.linalg.norm(Gh - o["Ghat"]) / np.linalg.norm(o["Ghat"])
+    assert relg <= tol["ghat"], f"relFro(P^T S) {relg:.3e}"
+    e.release()
+
+
+def _torch_reference(w, mode, M0, F0, steps):
+    """The reference's op sequence in fp32 on the GPU (oracle/torch_port.py with device tensors): per-step history, the
+    first-step gradient of M (and F)."""
+    from oracle.torch_port import TorchPortMapper, TorchPortMapperConstrained
+    tiny = lambda x: x[:4].cpu().numpy()
+    if mode == "constrained":
+        V = w["G"].shape[0]
+        m = TorchPortMapperConstrained(tiny(w["S"]), tiny(w["G"]), tiny(w["d"]), lambda_d=1, lambda_g1=1, lambda_g2=0, lambda_count=1,
+                                       lambda_f_reg=1, target_count=V, M0=np.zeros((4, 4)), F0=np.zeros(4))
+        m.F = F0.clone().requires_grad_(True)
+        params = None
+    else:
+        m = TorchPortMapper(tiny(w["S"]), tiny(w["G"]), d=tiny(w["d"]), lambda_g1=1, lambda_d=1, M0=np.zeros((4, 4)))
+    m.S, m.G, m.d = w["S"], w["G"], w["d"]                          # full-size tensors, already on the GPU
+    m.M = M0.clone().requires_grad_(True)
+    params = [m.M, m.F] if mode == "constrained" else [m.M]
+    opt = torch.optim.Adam(params, lr=0.1)
+    hist, grad = [], None
+    for i in range(steps):
+        total, terms = m.loss()
+        opt.zero_grad()
+        total.backward()
+        if i == 0:
+            grad = m.M.grad.detach().clone()
+        opt.step()
+        hist.append(terms)
+    del opt
+    return hist, grad
+
+
+@pytest.mark.parametrize("mode", ["cells", "constrained"])
+def test_full_size_cfg2_against_reference_op_sequence(mode):
+    """30k x 1k x 10k (118 x 40 tiles of 256^2, 4 gene tiles, 3 forward splits): gradient and 3-step trajectory of the HIP
+    path (bf16x3, the default) vs the reference's op sequence executed by PyTorch-ROCm fp32 on the same GPU."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.synthetic import make_workload, init_logits
+    from tangram_amd import _capi
+    C, K, V = 30000, 1000, 10000
+    w = make_workload(C, K, V, DEV, seed=0)
+    M0 = init_logits(C, V, DEV, seed=42)
+    F0 = torch.randn(C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7)) if mode == "constrained" else None
+    n = 3
+    ref_hist, ref_grad = _torch_reference(w, mode, M0, F0, n)
+    torch.cuda.empty_cache()
+    if mode == "constrained":
+        e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], F0=F0, mode="constrained", device=DEV, precision="bf16x3",
+                            lambdas=dict(lambda_g1=1, lambda_d=1, lambda_g2=0, lambda_count=1, lambda_f_reg=1), target_count=float(V))
+    else:
+        e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=DEV, precision="bf16x3", lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+    del M0
+    hist = e.new_history(n)
+    e.step(1, 0.1, hist, 0)
+    _, m1, _, _ = e.logits()
+    g = m1[:, :V] / (1.0 - BETA1)
+    # The fp32 autograd gradient itself carries ~1e-6 of round-off; entries of dM span 10 orders of magnitude (P underflows), so
+    # the comparison is in the Frobenius norm, plus a per-row check that no row is off (a wrong tile would be a whole block).
+    rel = float(torch.linalg.norm(g - ref_grad) / torch.linalg.norm(ref_grad))
+    assert rel <= 1e-4, f"first-step gradient rel err {rel:.3e}"
+    row_rel = torch.linalg.norm(g - ref_grad, dim=1) / torch.linalg.norm(ref_grad, dim=1).clamp_min(1e-30)
+    assert float(row_rel.max()) <= 1e-3, f"worst row {int(row_rel.argmax())}: {float(row_rel.max()):.3e}"
+    col_rel = torch.linalg.norm(g - ref_grad, dim=0) / torch.linalg.norm(ref_grad, dim=0).clamp_min(1e-30)
+    assert float(col_rel.max()) <= 1e-3, f"worst spot column {int(col_rel.argmax())}: {float(col_rel.max()):.3e}"
+    del g, ref_grad, row_rel, col_rel
+    e.step(n - 1, 0.1, hist, 1)
+    h = hist.cpu().numpy().astype(np.float64)
+    for k, col in (("main_loss", _capi.H_MAIN), ("kl_reg", _capi.H_KL)):
+        ref = np.array([float(t[k]) for t in ref_hist])
+        err = float(np.abs(h[:, col] - ref).max())
+        assert err <= 1e-5, f"{k}: {h[:, col]} vs {ref}"
+    ref_total = np.array([float(t["total_loss"]) for t in ref_hist])
+    scale = max(1.0, float(np.abs(ref_total).max()))        # constrained: |sum f - target| ~ 1e4 dominates the total
+    assert float(np.abs(h[:, _capi.H_TOTAL] - ref_total).max()) <= 2e-5 * scale, (h[:, _capi.H_TOTAL], ref_total)
+    if mode == "constrained":
+        for k, col in (("count_reg", _capi.H_COUNT), ("lambda_f_reg", _capi.H_FREG)):
+            ref = np.array([float(t[k]) for t in ref_hist])
+            assert float(np.abs(h[:, col] - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), (k, h[:, col], ref)
+    e.release()
+
+
+def test_rccl_one_rank_group_runs_the_sharded_step():
+    """RCCL itself on a real device: a 1-rank `nccl` process group drives the spot-sharded step (all three exchanges are
+    issued through RCCL) and must reproduce the single-engine run on the same inputs."""
+    import os
+    import torch.distributed as dist
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import ShardedMapperEngine
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dev = torch.device(DEV)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        C, K, V = 900, 150, 520
+        data = orc.make_synthetic(C, K, V, seed=2)
+        M0 = orc.reference_init_M(C, V, 8)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_r=1e-3, lambda_l2=1e-6)
+        n = 6
+        sh = ShardedMapperEngine(data["S"], data["G"], M0, data["d"], n_spots_total=V, device=dev, precision="bf16x3", lambdas=lam)
+        hs = sh.eng.new_history(n)
+        sh.run(n, 0.1, hs)
+        hs = sh.finalize_history(hs).cpu().numpy()
+        Ps = sh.result_full().cpu().numpy()
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=dev, precision="bf16x3", lambdas=lam)
+        h1 = e.new_history(n)
+        e.step(n, 0.1, h1)
+        h1 = h1.cpu().numpy()
+        for col in (0, 1, 2, 3, 4, 6):
+            np.testing.assert_allclose(hs[:, col], h1[:, col], rtol=0, atol=2e-6, err_msg=f"history column {col}")
+        assert float(np.abs(Ps - e.result().cpu().numpy()).max()) <= 1e-6
+    finally:
+        dist.destroy_process_group()
