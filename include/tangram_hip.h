@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 typedef enum tg_status {
     TG_OK = 0,
@@ -73,6 +73,9 @@ typedef struct tg_config {
     float lambda_getis_ord, lambda_moran, lambda_geary; /* spatial autocorrelation terms (:35-37, :159-187, :251-263); need Ws, Ws^T */
     int32_t nnz_s;                                      /* non-zeros of spatial_weights */
     float beta1, beta2, eps;                            /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 (:373) */
+    int32_t n_ranks;         /* 0 = the handle holds every spot and steps alone; >= 1 = it is one spot shard (one per GPU) and will be
+                                stepped through a communicator of that many ranks.  Sizes the gather buffer of the per-cell softmax
+                                statistics ([n_ranks][2 C + 64] floats of workspace).                                               */
 } tg_config;
 
 typedef struct tg_sizes {
@@ -110,11 +113,25 @@ enum { TG_H_TOTAL = 0, TG_H_MAIN = 1, TG_H_VG = 2, TG_H_KL = 3, TG_H_ENTROPY = 4
        TG_H_NB = 7, TG_H_CT = 8, TG_H_COUNT = 9, TG_H_FREG = 10, TG_H_GETIS = 11, TG_H_MORAN = 12, TG_H_GEARY = 13,
        TG_H_NTERMS = 16 };
 
-/* exchange buffers of the spot-sharded multi-GPU path (device pointers inside `workspace`) */
-enum { TG_X_GENESTAT = 0,   /* [2][Kp]  per-gene (dot, |Ghat|^2) partial sums   -> all-reduce(sum) */
-       TG_X_GNORM2 = 1,     /* [Kp]     per-gene |G|^2 (set-up)                 -> all-reduce(sum) */
-       TG_X_ROWQ = 2,       /* [6][C]   per-cell row dots r_c and friends       -> all-reduce(sum) */
-       TG_X_ROWPAIR = 3     /* [2][C]   per-cell (max, sum exp) of the new row  -> all-gather      */ };
+/* ---- communicator of the spot-sharded multi-GPU path (the reference has no distributed code) ----------
+ * One process per GPU; rank g owns the spots V_g: M[:, V_g] + Adam moments, G[V_g], d[V_g]; S is replicated.  Per iteration exactly
+ * three small vectors cross GPUs, all issued by the library itself on the handle's stream, between its own kernels:
+ *   per-gene cosine statistics [2][Kp]            all-reduce(sum)   after the forward GEMM
+ *   per-cell softmax-backward row dots [1|6][C]   all-reduce(sum)   after the backward GEMM
+ *   per-cell (max, sum exp) of the new logits     all-gather        after the Adam update   (+ 2 history scalars per rank)
+ * A tg_comm is either RCCL (librccl.so is dlopen'ed: collectives run on the handle's stream, no host code between the phases of a
+ * step) or a pair of callbacks (any other transport: torch.distributed/gloo in the CPU tests, in-process shards in the GPU tests). */
+typedef struct tg_comm tg_comm;
+typedef int (*tg_all_reduce_sum_fn)(void* ctx, float* buf_dev, size_t n_floats, void* hip_stream);          /* in place; 0 = ok */
+typedef int (*tg_all_gather_fn)(void* ctx, const float* send_dev, float* recv_dev, size_t n_floats_per_rank, void* hip_stream);
+int tg_comm_create_callbacks(int world, int rank, tg_all_reduce_sum_fn all_reduce_sum, tg_all_gather_fn all_gather, void* ctx,
+                             tg_comm** out);
+/* RCCL: rank 0 calls tg_comm_rccl_unique_id and hands the 128 bytes to every rank (any out-of-band channel, e.g. a
+ * torch.distributed broadcast); every rank then calls tg_comm_create_rccl (collective).  librccl_path: the librccl.so to bind
+ * (the one PyTorch-ROCm ships is the natural choice); NULL = "librccl.so" by the loader's search path.                        */
+int tg_comm_rccl_unique_id(const char* librccl_path, void* id128_out);
+int tg_comm_create_rccl(const char* librccl_path, const void* id128, int world, int rank, tg_comm** out);
+void tg_comm_destroy(tg_comm* c);
 
 int tg_abi_version(void);
 const char* tg_last_error(void);
@@ -134,16 +151,11 @@ void tg_mapper_destroy(tg_mapper* m);
  * into history_dev[(first_row + i) * TG_H_NTERMS ...] (device memory, may be NULL).                 */
 int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row);
 
-/* Spot-sharded multi-GPU variant of one step, split at the three points where per-gene / per-cell
- * vectors must be reduced across GPUs.  The caller performs the collectives on the
- * exchange buffers between the phases:
- *   phase 0 (once, after create): all-reduce TG_X_GNORM2, then tg_mapper_phase(m, 0, ...)
- *   phase 1: forward + local gene statistics        -> all-reduce TG_X_GENESTAT
- *   phase 2: loss, dGhat, backward row dots         -> all-reduce TG_X_ROWQ
- *   phase 3: backward update + Adam + local softmax statistics -> all-gather TG_X_ROWPAIR into `gathered_dev`
- *   phase 4: merge the gathered [nranks][2][C] statistics                                            */
-int tg_mapper_phase(tg_mapper* m, int phase, float lr, float* history_row_dev, const float* gathered_dev, int nranks);
-int tg_mapper_exchange_buffer(tg_mapper* m, int which, float** ptr_dev, size_t* n_floats);
+/* Spot-sharded multi-GPU run: attach a communicator to a handle created with n_spots < n_spots_total (collective; performs the
+ * set-up exchanges: |G_k|^2 and sum(d) all-reduced, softmax statistics of the initial logits gathered).  Afterwards
+ * tg_mapper_step runs the sharded schedule: same kernels on this rank's spots + the three exchanges above per iteration; the
+ * history rows it writes are GLOBAL (identical on every rank).  The communicator must outlive the handle.                      */
+int tg_mapper_attach_comm(tg_mapper* m, tg_comm* comm);
 
 /* Replaces `softmax(self.M, dim=1).cpu().numpy()` (mapping_optimizer.py:407; :637-638 constrained):
  * P_out_dev [C][V] dense, F_out_dev [C] (sigmoid(F)) or NULL.                                       */

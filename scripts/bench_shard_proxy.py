@@ -1,5 +1,5 @@
 """Per-rank cost of the spot-sharded multi-GPU step on ONE GPU: rank 0 of an 8-way split of cfg2 (30k x 1k x 1250 of
-10 000 spots) driven through the real ShardedMapperEngine (phases + torch.distributed collectives on a 1-rank RCCL
+10 000 spots) driven through the real ShardedMapperEngine (the C library issues kernels + RCCL collectives on a 1-rank
 group), so the host-side enqueue cost and the kernel time of a shard are both visible."""
 import json
 import os

@@ -12,7 +12,7 @@ for r in $(seq 1 $ROUNDS); do
   [ -f $lib ] || continue
   n=$(basename $lib .so)
   for P in $PRECS; do
-    TANGRAM_AMD_LIB=$lib timeout 600 python bench.py --steps 20 --warmup 4 --precision $P --no-cpu-baseline --no-alt > $O/${n}_${P}_r$r.json 2> $O/${n}_${P}_r$r.err || echo "FAIL $n $P"
+    TANGRAM_AMD_LIB=$lib timeout 600 python bench.py --steps 40 --warmup 5 --precision $P --no-cpu-baseline --no-alt > $O/${n}_${P}_r$r.json 2> $O/${n}_${P}_r$r.err || echo "FAIL $n $P"
   done
  done
 done

@@ -13,12 +13,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TANGRAM_AMD_LIB") or os.path.join(_HERE, "csrc", "libtangram_hip.so")   # env: kernel A/B experiments
 
-TG_ABI_VERSION = 1
+TG_ABI_VERSION = 2
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 H_NTERMS = 16
 H_TOTAL, H_MAIN, H_VG, H_KL, H_ENTROPY, H_L1, H_L2, H_NB, H_CT, H_COUNT, H_FREG, H_GETIS, H_MORAN, H_GEARY = range(14)
-X_GENESTAT, X_GNORM2, X_ROWQ, X_ROWPAIR = range(4)
 
 
 class TgConfig(ct.Structure):
@@ -30,7 +29,11 @@ class TgConfig(ct.Structure):
                  "lambda_count", "lambda_f_reg", "target_count", "lambda_neighborhood_g1", "lambda_ct_islands")] + \
                [(n, ct.c_int32) for n in ("n_cell_types", "nnz_w", "nnz_n")] + \
                [(n, ct.c_float) for n in ("lambda_getis_ord", "lambda_moran", "lambda_geary")] + [("nnz_s", ct.c_int32)] + \
-               [(n, ct.c_float) for n in ("beta1", "beta2", "eps")]
+               [(n, ct.c_float) for n in ("beta1", "beta2", "eps")] + [("n_ranks", ct.c_int32)]
+
+
+ALL_REDUCE_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_void_p)                 # tg_all_reduce_sum_fn
+ALL_GATHER_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_void_p)    # tg_all_gather_fn
 
 
 class TgSizes(ct.Structure):
@@ -58,8 +61,12 @@ def _declare(lib):
     lib.tg_mapper_destroy.argtypes = [vp]
     lib.tg_mapper_destroy.restype = None
     lib.tg_mapper_step.argtypes = [vp, i32, f32, vp, i32]
-    lib.tg_mapper_phase.argtypes = [vp, i32, f32, vp, vp, i32]
-    lib.tg_mapper_exchange_buffer.argtypes = [vp, i32, ct.POINTER(vp), ct.POINTER(ct.c_size_t)]
+    lib.tg_comm_create_callbacks.argtypes = [i32, i32, ALL_REDUCE_FN, ALL_GATHER_FN, vp, ct.POINTER(vp)]
+    lib.tg_comm_rccl_unique_id.argtypes = [ct.c_char_p, vp]
+    lib.tg_comm_create_rccl.argtypes = [ct.c_char_p, vp, i32, i32, ct.POINTER(vp)]
+    lib.tg_comm_destroy.argtypes = [vp]
+    lib.tg_comm_destroy.restype = None
+    lib.tg_mapper_attach_comm.argtypes = [vp, vp]
     lib.tg_mapper_result.argtypes = [vp, vp, vp]
     lib.tg_mapper_project.argtypes = [vp, vp]
     lib.tg_mapper_project_genes.argtypes = [vp, vp, ct.c_int64, i32, vp, ct.c_int64, i32]
@@ -72,15 +79,16 @@ def _declare(lib):
     lib.tg_mapper_profile.argtypes = [vp, i32]
     lib.tg_mapper_profile_read.argtypes = [vp, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_float), ct.POINTER(i32), i32,
                                            ct.POINTER(i32)]
-    for name in ("tg_query_sizes", "tg_mapper_create", "tg_mapper_step", "tg_mapper_phase",
-                 "tg_mapper_exchange_buffer", "tg_mapper_result", "tg_mapper_project", "tg_mapper_project_genes",
+    for name in ("tg_query_sizes", "tg_mapper_create", "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id",
+                 "tg_comm_create_rccl", "tg_mapper_attach_comm", "tg_mapper_result", "tg_mapper_project", "tg_mapper_project_genes",
                  "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile", "tg_mapper_profile_read", "tg_mapper_validate"):
         getattr(lib, name).restype = i32
     return lib
 
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
-           "tg_mapper_step", "tg_mapper_phase", "tg_mapper_exchange_buffer", "tg_mapper_result",
+           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_destroy",
+           "tg_mapper_attach_comm", "tg_mapper_result",
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
            "tg_mapper_profile_read", "tg_mapper_validate"]
 
@@ -95,7 +103,7 @@ def lib():
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). tangram_amd has no CPU fallback.")
         _lib = _declare(ct.CDLL(LIB_PATH))
         if _lib.tg_abi_version() != TG_ABI_VERSION:
-            raise RuntimeError("libtangram_hip.so ABI version mismatch")
+            raise RuntimeError("libtangram_hip.so ABI version mismatch (rebuild: python -c 'import __graft_entry__ as g; g.build()')")
     return _lib
 
 

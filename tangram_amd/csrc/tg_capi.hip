@@ -102,7 +102,8 @@ struct TgLayout {
         o_gfrac, o_rowent, o_extra, o_WG, o_Y, o_nbpart, o_nbstat, o_wgn2, o_nbcoef, o_ctmask, o_ctpart, o_csr[6][3],
         o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
         o_accmpart, o_accm, o_actnorm, total;
-    int T_ct, Tp, has_nb, has_ct, has_ac, bands;
+    int T_ct, Tp, has_nb, has_ct, has_ac, bands, nranks;
+    size_t o_gathered, pair_stride;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
@@ -130,6 +131,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     if (cfg->mode != TG_MODE_MAPPER && cfg->mode != TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_INVALID, "unknown mode %d", cfg->mode);
     if (cfg->lambda_g1 == 0.f) return tg_fail(TG_ERR_INVALID, "lambda_g1 cannot be 0.");   // mapping_utils.py:206-207
     if (cfg->has_d_source && !cfg->has_density) return tg_fail(TG_ERR_INVALID, "d_source requires d");
+    if (cfg->n_ranks < 0 || cfg->n_ranks > 4096) return tg_fail(TG_ERR_INVALID, "n_ranks out of range");
     memset(L, 0, sizeof *L);
     L->C = cfg->n_cells; L->K = cfg->n_genes; L->V = cfg->n_spots;
     L->Vtot = cfg->n_spots_total > 0 ? cfg->n_spots_total : cfg->n_spots;
@@ -184,7 +186,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_Gpart = take((size_t)L->nsplit * L->Vr * L->Kp * 4);
     L->o_genepart = take((size_t)L->nrb * 2 * L->Kp * 4);
     L->o_genestat = take((size_t)2 * L->Kp * 4);
-    L->o_gnorm2 = take((size_t)L->Kp * 4);
+    L->o_gnorm2 = take((size_t)(L->Kp + 64) * 4);         // [Kp] |G_k|^2, then [Kp] = sum of the density prior (set-up exchange vector)
     L->o_voxstat = take((size_t)((L->Kp + TG_GH_COLS - 1) / TG_GH_COLS) * 2 * L->Vr * 4);
     L->o_vnorm2 = take((size_t)L->Vr * 4);
     L->o_d = take((size_t)L->Vr * 4);
@@ -199,7 +201,10 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     const size_t np1 = L->full ? TGP1_N : 1;
     L->o_part = take((size_t)L->nvt * np1 * L->C * 4);
     L->o_rowq = take((size_t)TGP1_N * L->C * 4);
-    L->o_rowpair = take((size_t)2 * L->C * 4);
+    L->pair_stride = (size_t)2 * L->C + TG_PAIR_TAIL;     // (max, sum exp) pairs + the per-rank history partials
+    L->o_rowpair = take(L->pair_stride * 4);
+    L->nranks = cfg->n_ranks > 1 ? cfg->n_ranks : 1;
+    if (cfg->n_ranks >= 1 || L->Vtot != L->V) L->o_gathered = take((size_t)L->nranks * L->pair_stride * 4);   // (n_ranks = 1: a 1-rank communicator)
     L->o_scal = take(64 * 4);
     L->o_fsum = take(64 * 4);
     L->o_X = take((size_t)L->C * L->Vp * 4);
@@ -270,6 +275,7 @@ struct tg_mapper {
     bool stream_once;                                // the per-iteration arrays exceed the MALL: non-temporal accesses (tg_ld_stream)
     bool fin_pending;
     TgFinalizeArgs fin_args;
+    tg_comm* comm;                                   // spot-sharded run: the communicator (borrowed), else null
     // profiling
     bool prof;
     std::vector<std::string> prof_names;
@@ -335,15 +341,18 @@ static int tg_softmax_stats_from_scratch(tg_mapper* m) {
     return TG_OK;
 }
 
-static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize, bool want_pair) {
+static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize, bool want_pair, float* global_hist_row = nullptr,
+                    int rank = 0) {
     const TgLayout& L = m->L;
     TgMergeArgs a;
-    a.part = parts; a.nparts = nparts; a.C = L.C;
+    a.part = parts; a.nparts = nparts; a.C = L.C; a.stride = L.pair_stride;
     a.rshift = finalize ? m->fp(L.o_rshift) : nullptr;
     a.rinvz = m->fp(L.o_rinvz);
     a.rmul = m->fp(L.o_rmul); a.rscale = m->fp(L.o_rscale);
     a.pair_out = want_pair ? m->fp(L.o_rowpair) : nullptr;
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
+    a.hist = global_hist_row; a.rank = rank;
+    a.lambda_g2 = m->cfg.lambda_g2; a.lambda_d = m->cfg.lambda_d; a.has_density = m->cfg.has_density;
     TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
     tg_prof_mark(m, "tg_merge_stats");
     TG_LAUNCH_CK();
@@ -501,7 +510,7 @@ static int tg_launch_filter(tg_mapper* m, bool update, float lr, float* hist_row
     float* F = (float*)(m->st + L.s_F);
     a.F = F; a.mF = F + L.Cp; a.vF = F + 2 * (size_t)L.Cp;
     a.fgate = m->fp(L.o_fgate); a.fsum = m->fp(L.o_fsum); a.rowq = m->fp(L.o_rowq);
-    a.d = m->fp(L.o_d); a.V = L.V; a.hist = hist_row ? hist_row : m->fp(L.o_scal);
+    a.dsum = m->fp(L.o_gnorm2) + L.Kp; a.hist = hist_row ? hist_row : m->fp(L.o_scal);
     a.C = L.C; a.do_update = update ? 1 : 0; a.has_density = m->cfg.has_density;
     a.lambda_d = m->cfg.lambda_d; a.lambda_count = m->cfg.lambda_count; a.lambda_f_reg = m->cfg.lambda_f_reg;
     a.target_count = m->cfg.target_count;
@@ -529,7 +538,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     m->cfg = *cfg; m->L = L;
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
-    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false;
+    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->comm = nullptr;
     // M, Adam m, v (fp32) and X (fp32 or bf16) of this handle against the 256 MB MALL, with room left for the GEMM operands
     m->stream_once = (size_t)L.C * L.Vp * (12 + (cfg->precision == TG_PREC_BF16 ? 2 : 4)) > ((size_t)192 << 20);
     m->s_adam = nullptr; m->s_fwd = nullptr;
@@ -564,6 +573,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
               m->fp(L.o_gnorm2), 1.f);
     TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream,
               (const float*)(m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp), L.nrb, L.Kp, m->fp(L.o_gfrac), 1.f / (float)L.V);
+    if (cfg->has_density) TG_LAUNCH(tg_vec_sum, 1, 1, 1024, 64, m->stream, (const float*)m->fp(L.o_d), L.V, m->fp(L.o_gnorm2) + L.Kp);
     if ((L.has_nb || L.has_ct || L.has_ac) && (rc = tg_setup_spatial(m, in))) return bail(rc);
     if (L.has_ac && (rc = tg_setup_autocorr(m))) return bail(rc);
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
@@ -662,6 +672,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     f.nbcoef = L.has_nb ? m->fp(L.o_nbcoef) : nullptr;
     f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.V;
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
+    f.part_out = m->comm ? m->fp(L.o_rowpair) + 2 * (size_t)L.C : nullptr;       // spot shard: this rank's parts of the spot sums
     TgEmitArgs e;
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
@@ -670,8 +681,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     e.fin = f;
     // Without spatial terms every gradient coefficient is a local function of the reduced statistics: the emit kernel
     // derives them itself and the scalars of the history row are left to one extra workgroup of the update kernel.
-    // (single GPU only: on a spot shard tg_hist_regs has to see the base row before the row sums are all-reduced)
-    const bool self = !e.extra && L.bands == 1 && L.Vtot == L.V && (size_t)(2 * L.Kp + 2 * TG_RB) * 4 <= 48 * 1024;
+    const bool self = !e.extra && L.bands == 1 && (L.Vtot == L.V || m->comm) && (size_t)(2 * L.Kp + 2 * TG_RB) * 4 <= 48 * 1024;
     if (self) {
         m->fin_args = f; m->fin_pending = true;
         TG_LAUNCH((tg_dghat_emit<PR, false, true>), (L.V + TG_RB - 1) / TG_RB, 1, 256, (2 * L.Kp + 2 * TG_RB) * 4, m->stream, e);
@@ -746,6 +756,31 @@ static void tg_launch_hist_regs(tg_mapper* m, tg_stream_t stream, float* hist_ro
     TG_LAUNCH(tg_hist_regs, 1, 1, 1024, 64, stream, h);
 }
 
+// arguments shared by the update kernels and the row-dot pass, for the cells [c0, c1)
+static TgUpdateArgs tg_update_args(tg_mapper* m, float lr, bool finalize, int c0, int c1) {
+    const TgLayout& L = m->L;
+    TgUpdateArgs u;
+    u.X = m->fp(L.o_X);
+    u.M = (float*)(m->st + L.s_M); u.am = (float*)(m->st + L.s_m1); u.av = (float*)(m->st + L.s_m2);
+    u.rshift = m->fp(L.o_rshift); u.rinvz = m->fp(L.o_rinvz);
+    u.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
+    u.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
+    u.vcoef = m->fp(L.o_vcoef); u.r = m->fp(L.o_rowq);
+    u.pair_out = m->fp(L.o_rowpair); u.rowq_out = m->fp(L.o_rowq);
+    u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_mul = m->fp(L.o_rmul); u.new_scale = m->fp(L.o_rscale);
+    u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0; u.c_begin = c0; u.c_end = c1;
+    u.lambda_r = m->cfg.lambda_r; u.lambda_l1 = m->cfg.lambda_l1; u.lambda_l2 = m->cfg.lambda_l2;
+    const double t = (double)(m->step + 1);
+    u.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
+    u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
+    u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
+    u.fin_on = 0;
+    return u;
+}
+
+// backward GEMM with the row-dot epilogue + the sum of its per-spot-tile partials (rows too long for tg_adam_rowpass; spot shards
+// take the same two kernels in tg_one_step_sharded).  A separate row-dot pass over the stored X (one wave per row) was measured
+// instead of the epilogue: 202 + 60 us against 247 + 7 us on a 1/8 spot shard of cfg2, i.e. no better (profiles/r02/run3).
 template <class PR>
 static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
@@ -781,21 +816,7 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     const TgLayout& L = m->L;
     const bool whole = c1 < 0;
     if (whole) { stream = m->stream; c0 = 0; c1 = L.C; }
-    TgUpdateArgs u;
-    u.X = m->fp(L.o_X);
-    u.M = (float*)(m->st + L.s_M); u.am = (float*)(m->st + L.s_m1); u.av = (float*)(m->st + L.s_m2);
-    u.rshift = m->fp(L.o_rshift); u.rinvz = m->fp(L.o_rinvz);
-    u.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
-    u.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
-    u.vcoef = m->fp(L.o_vcoef); u.r = m->fp(L.o_rowq);
-    u.pair_out = m->fp(L.o_rowpair); u.rowq_out = m->fp(L.o_rowq);
-    u.new_shift = m->fp(L.o_rshift); u.new_invz = m->fp(L.o_rinvz); u.new_mul = m->fp(L.o_rmul); u.new_scale = m->fp(L.o_rscale);
-    u.C = L.C; u.V = L.V; u.Vp = L.Vp; u.Vr = L.Vr; u.finalize = finalize ? 1 : 0; u.c_begin = c0;
-    u.lambda_r = m->cfg.lambda_r; u.lambda_l1 = m->cfg.lambda_l1; u.lambda_l2 = m->cfg.lambda_l2;
-    const double t = (double)(m->step + 1);
-    u.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
-    u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
-    u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
+    TgUpdateArgs u = tg_update_args(m, lr, finalize, c0, c1);
     const bool x16 = (m->cfg.precision == TG_PREC_BF16);     // PrecBF16::X16
     u.fin_on = 0;
     int extra_wg = 0;
@@ -890,7 +911,169 @@ static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool f
     return TG_OK;
 }
 
+// ---- spot-sharded multi-GPU path --------------------------------------------------------------------------------------
+#ifndef TG_SIM
+#include <dlfcn.h>
+#endif
+struct tg_comm {
+    int world, rank;
+    tg_all_reduce_sum_fn ar; tg_all_gather_fn ag; void* ctx;       // callback transport
+    // RCCL transport (librccl.so bound at run time: the library itself has no link-time dependency on it)
+    void* lib; void* nccl;
+    int (*p_allreduce)(const void*, void*, size_t, int, int, void*, void*);
+    int (*p_allgather)(const void*, void*, size_t, int, void*, void*);
+    int (*p_destroy)(void*);
+    const char* (*p_errstr)(int);
+};
+struct tg_nccl_id { char internal[128]; };     // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+enum { TG_NCCL_FLOAT = 7, TG_NCCL_SUM = 0 };   // ncclFloat32, ncclSum (rccl.h)
+
+extern "C" int tg_comm_create_callbacks(int world, int rank, tg_all_reduce_sum_fn ar, tg_all_gather_fn ag, void* ctx, tg_comm** out) {
+    if (!out || !ar || !ag || world < 1 || rank < 0 || rank >= world) return tg_fail(TG_ERR_INVALID, "bad communicator arguments");
+    tg_comm* c = new (std::nothrow) tg_comm();
+    if (!c) return tg_fail(TG_ERR_INVALID, "out of host memory");
+    c->world = world; c->rank = rank; c->ar = ar; c->ag = ag; c->ctx = ctx; c->lib = nullptr; c->nccl = nullptr;
+    *out = c;
+    return TG_OK;
+}
+
+#ifndef TG_SIM
+static void* tg_rccl_open(const char* path) {
+    void* h = nullptr;
+    if (path && *path) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return h;
+}
+#endif
+
+extern "C" int tg_comm_rccl_unique_id(const char* librccl_path, void* id128_out) {
+#ifdef TG_SIM
+    (void)librccl_path; (void)id128_out;
+    return tg_fail(TG_ERR_UNSUPPORTED, "RCCL is not available in the emulated build");
+#else
+    if (!id128_out) return tg_fail(TG_ERR_INVALID, "null id buffer");
+    void* h = tg_rccl_open(librccl_path);
+    if (!h) return tg_fail(TG_ERR_HIP, "cannot load librccl.so (%s)", dlerror());
+    auto get_id = (int (*)(tg_nccl_id*))dlsym(h, "ncclGetUniqueId");
+    if (!get_id) return tg_fail(TG_ERR_HIP, "librccl.so has no ncclGetUniqueId");
+    const int e = get_id((tg_nccl_id*)id128_out);
+    if (e) return tg_fail(TG_ERR_HIP, "ncclGetUniqueId failed with %d", e);
+    return TG_OK;
+#endif
+}
+
+extern "C" int tg_comm_create_rccl(const char* librccl_path, const void* id128, int world, int rank, tg_comm** out) {
+#ifdef TG_SIM
+    (void)librccl_path; (void)id128; (void)world; (void)rank; (void)out;
+    return tg_fail(TG_ERR_UNSUPPORTED, "RCCL is not available in the emulated build");
+#else
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return tg_fail(TG_ERR_INVALID, "bad communicator arguments");
+    void* h = tg_rccl_open(librccl_path);
+    if (!h) return tg_fail(TG_ERR_HIP, "cannot load librccl.so (%s)", dlerror());
+    tg_comm* c = new (std::nothrow) tg_comm();
+    if (!c) return tg_fail(TG_ERR_INVALID, "out of host memory");
+    c->world = world; c->rank = rank; c->ar = nullptr; c->ag = nullptr; c->ctx = nullptr; c->lib = h; c->nccl = nullptr;
+    auto init = (int (*)(void**, int, tg_nccl_id, int))dlsym(h, "ncclCommInitRank");
+    c->p_allreduce = (int (*)(const void*, void*, size_t, int, int, void*, void*))dlsym(h, "ncclAllReduce");
+    c->p_allgather = (int (*)(const void*, void*, size_t, int, void*, void*))dlsym(h, "ncclAllGather");
+    c->p_destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    c->p_errstr = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!init || !c->p_allreduce || !c->p_allgather || !c->p_destroy) { delete c; return tg_fail(TG_ERR_HIP, "librccl.so lacks a required entry point"); }
+    tg_nccl_id id;
+    memcpy(&id, id128, sizeof id);
+    const int e = init(&c->nccl, world, id, rank);
+    if (e) { const char* msg = c->p_errstr ? c->p_errstr(e) : "?"; delete c; return tg_fail(TG_ERR_HIP, "ncclCommInitRank failed with %d (%s)", e, msg); }
+    *out = c;
+    return TG_OK;
+#endif
+}
+
+extern "C" void tg_comm_destroy(tg_comm* c) {
+    if (!c) return;
+#ifndef TG_SIM
+    if (c->nccl && c->p_destroy) (void)c->p_destroy(c->nccl);
+#endif
+    delete c;
+}
+
+static int tg_comm_all_reduce(tg_mapper* m, float* buf, size_t n) {
+    tg_comm* c = m->comm;
+    int e;
+    if (c->nccl) e = c->p_allreduce(buf, buf, n, TG_NCCL_FLOAT, TG_NCCL_SUM, c->nccl, (void*)m->stream);
+    else e = c->ar(c->ctx, buf, n, (void*)m->stream);
+    if (e) return tg_fail(TG_ERR_HIP, "all-reduce of %zu floats failed with %d", n, e);
+    tg_prof_mark(m, "exchange_all_reduce");
+    return TG_OK;
+}
+static int tg_comm_all_gather(tg_mapper* m, const float* send, float* recv, size_t n) {
+    tg_comm* c = m->comm;
+    int e;
+    if (c->nccl) e = c->p_allgather(send, recv, n, TG_NCCL_FLOAT, c->nccl, (void*)m->stream);
+    else e = c->ag(c->ctx, send, recv, n, (void*)m->stream);
+    if (e) return tg_fail(TG_ERR_HIP, "all-gather of %zu floats per rank failed with %d", n, e);
+    tg_prof_mark(m, "exchange_all_gather");
+    return TG_OK;
+}
+
+// gather every rank's (max, sum exp) block, merge; `hist_row`: also turn this rank's history row into the global one
+static int tg_exchange_row_stats(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    int rc = tg_comm_all_gather(m, m->fp(L.o_rowpair), m->fp(L.o_gathered), L.pair_stride);
+    if (rc) return rc;
+    return tg_merge(m, m->fp(L.o_gathered), m->comm->world, /*finalize=*/true, /*want_pair=*/false, hist_row, m->comm->rank);
+}
+
+extern "C" int tg_mapper_attach_comm(tg_mapper* m, tg_comm* comm) {
+    if (!m || !m->ready || !comm) return tg_fail(TG_ERR_STATE, "mapper not ready or null communicator");
+    const TgLayout& L = m->L;
+    if (m->step != 0) return tg_fail(TG_ERR_STATE, "attach the communicator before the first step");
+    if (comm->world > L.nranks) return tg_fail(TG_ERR_INVALID, "communicator of %d ranks but the handle was sized for n_ranks = %d", comm->world, L.nranks);
+    if (!L.o_gathered) return tg_fail(TG_ERR_INVALID, "the handle was not created as a spot shard (n_ranks / n_spots_total)");
+    if (L.has_nb || L.has_ct || L.has_ac) return tg_fail(TG_ERR_UNSUPPORTED, "spatial terms need the whole spot graph on one GPU");
+    if (L.bands > 1) return tg_fail(TG_ERR_UNSUPPORTED, "the cell-band pipeline is a single-GPU schedule");
+    m->comm = comm;
+    // set-up exchange: |G_k|^2 over all spots and the total of the density prior, then the softmax statistics of the initial logits
+    int rc = tg_comm_all_reduce(m, m->fp(L.o_gnorm2), (size_t)L.Kp + 1);
+    if (rc) return rc;
+    if ((rc = tg_softmax_stats_from_scratch(m))) return rc;
+    return tg_exchange_row_stats(m, nullptr);
+}
+
+// One iteration on a spot shard: the kernels of tg_one_step on this rank's spots, with the three exchanges issued between them
+// on the same stream (RCCL: no host code, no second stream, no event between a kernel and the collective that consumes its output).
+template <class PR>
+static int tg_one_step_sharded(tg_mapper* m, float lr, float* hist_row) {
+    const TgLayout& L = m->L;
+    int rc;
+    if ((rc = tg_launch_forward<PR>(m))) return rc;
+    if ((rc = tg_launch_ghat_stats(m))) return rc;
+    if ((rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
+    if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;                                    // (coefficients; dGhat operand image)
+    tg_launch_bwd<PR>(m, m->stream, 0, L.nct);                                                // X + row-dot partials of this rank's spots
+    tg_prof_mark(m, "tg_bwd_kernel");
+    tg_launch_rowsum(m, m->stream, 0, L.C);
+    tg_prof_mark(m, "tg_rowsum_parts");
+    if (tg_launch_failed()) return tg_launch_status();
+    if ((rc = tg_comm_all_reduce(m, m->fp(L.o_rowq), (size_t)(L.full ? TGP1_N : 1) * L.C))) return rc;   // E3: row dots (+ regulariser row sums)
+    if ((rc = tg_launch_update(m, lr, false))) return rc;       // Adam; local (max, sum exp); deferred history row by its extra workgroup
+    if (L.full) {                                               // the row sums are global now: every rank adds the same scalars
+        tg_launch_hist_regs(m, m->stream, hist_row);
+        tg_prof_mark(m, "tg_hist_regs");
+    }
+    if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;   // replicated F: same result on every rank
+    m->step += 1;
+    return tg_exchange_row_stats(m, hist_row);                  // E1: statistics of the new rows (+ globalise the history row)
+}
+
 static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row, bool prelaunched = false, bool prelaunch_next = false) {
+    if (m->comm) {
+        switch (m->cfg.precision) {
+            case TG_PREC_F32: return tg_one_step_sharded<PrecF32>(m, lr, hist_row);
+            case TG_PREC_BF16: return tg_one_step_sharded<PrecBF16>(m, lr, hist_row);
+            default: return tg_one_step_sharded<PrecBF16x3>(m, lr, hist_row);
+        }
+    }
     if (m->L.bands > 1 && !m->prof) {
         switch (m->cfg.precision) {
             case TG_PREC_F32: return tg_one_step_pipelined<PrecF32>(m, lr, hist_row, prelaunched, prelaunch_next);
@@ -908,6 +1091,7 @@ static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row, bool prelau
 extern "C" int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (n_steps < 0) return tg_fail(TG_ERR_INVALID, "n_steps < 0");
+    if (!m->comm && m->L.Vtot != m->L.V) return tg_fail(TG_ERR_STATE, "a spot shard needs tg_mapper_attach_comm before it can step");
     const bool pipelined = m->L.bands > 1 && !m->prof;
     bool prelaunched = false;
     for (int i = 0; i < n_steps; ++i) {
@@ -916,63 +1100,6 @@ extern "C" int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* histor
         int rc = tg_dispatch_step(m, lr, row, prelaunched, next);
         if (rc) return rc;
         prelaunched = next;
-    }
-    return TG_OK;
-}
-
-template <class PR>
-static int tg_phase_impl(tg_mapper* m, int phase, float lr, float* hist_row, const float* gathered, int nranks) {
-    int rc = TG_OK;
-    switch (phase) {
-        case 0: break;   // gnorm2 has been all-reduced in place by the caller; nothing else to do
-        case 1:
-            if ((rc = tg_launch_forward<PR>(m))) return rc;
-            rc = tg_launch_ghat_stats(m);
-            break;
-        case 2:
-            if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
-            rc = tg_launch_rowdots<PR>(m, hist_row);
-            break;
-        case 3: {
-            const bool deferred = m->fin_pending;       // world = 1: the history row was left to the update kernel (tg_dghat_emit<SELF>)
-            if ((rc = tg_launch_update(m, lr, false))) return rc;      // leaves the local (max, Z) pairs in TG_X_ROWPAIR
-            if (m->L.full && deferred) {                // ... so the regulariser scalars can only be added now (as tg_one_step does)
-                tg_launch_hist_regs(m, m->stream, hist_row);
-                tg_prof_mark(m, "tg_hist_regs");
-            }
-            if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
-            m->step += 1;
-            break;
-        }
-        case 4:
-            if (!gathered || nranks < 1) return tg_fail(TG_ERR_INVALID, "phase 4 needs the gathered statistics");
-            rc = tg_merge(m, gathered, nranks, true, false);
-            break;
-        default: return tg_fail(TG_ERR_INVALID, "unknown phase %d", phase);
-    }
-    if (rc) return rc;
-    TG_LAUNCH_CK();
-    return TG_OK;
-}
-
-extern "C" int tg_mapper_phase(tg_mapper* m, int phase, float lr, float* history_row_dev, const float* gathered_dev, int nranks) {
-    if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
-    switch (m->cfg.precision) {
-        case TG_PREC_F32: return tg_phase_impl<PrecF32>(m, phase, lr, history_row_dev, gathered_dev, nranks);
-        case TG_PREC_BF16: return tg_phase_impl<PrecBF16>(m, phase, lr, history_row_dev, gathered_dev, nranks);
-        default: return tg_phase_impl<PrecBF16x3>(m, phase, lr, history_row_dev, gathered_dev, nranks);
-    }
-}
-
-extern "C" int tg_mapper_exchange_buffer(tg_mapper* m, int which, float** ptr_dev, size_t* n_floats) {
-    if (!m || !ptr_dev || !n_floats) return tg_fail(TG_ERR_INVALID, "null argument");
-    const TgLayout& L = m->L;
-    switch (which) {
-        case TG_X_GENESTAT: *ptr_dev = m->fp(L.o_genestat); *n_floats = (size_t)2 * L.Kp; break;
-        case TG_X_GNORM2: *ptr_dev = m->fp(L.o_gnorm2); *n_floats = (size_t)L.Kp; break;
-        case TG_X_ROWQ: *ptr_dev = m->fp(L.o_rowq); *n_floats = (size_t)(L.full ? TGP1_N : 1) * L.C; break;
-        case TG_X_ROWPAIR: *ptr_dev = m->fp(L.o_rowpair); *n_floats = (size_t)2 * L.C; break;
-        default: return tg_fail(TG_ERR_INVALID, "unknown exchange buffer %d", which);
     }
     return TG_OK;
 }
@@ -1100,8 +1227,9 @@ extern "C" int tg_mapper_set_step(tg_mapper* m, int64_t step) {
     int rc = TG_OK;
     if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, false, 0.f, nullptr))) return rc;
     rc = tg_softmax_stats_from_scratch(m);
-    if (!rc) rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false);
-    return rc;
+    if (rc) return rc;
+    if (m->comm) return tg_exchange_row_stats(m, nullptr);          // collective: every rank restores its shard and calls this
+    return tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false);
 }
 
 extern "C" int tg_mapper_profile(tg_mapper* m, int enable) {

@@ -38,6 +38,15 @@ template <bool STREAM, class T> TG_DEV void tg_st_stream(const T& v, T* p) {
     if constexpr (STREAM) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
+#ifndef TG_FWD_STAGGER
+#define TG_FWD_STAGGER (-1)   // forward kernel A-operand staging schedule: 0 = block after the MFMAs, 1 / 2 = phase-shifted halves
+#endif                        // (waves 0-3 / 4-7 early); -1 = per precision (measured, see tg_fwd_kernel)
+#ifndef TG_YOUNG_PRIO
+#define TG_YOUNG_PRIO 0       // experiment: static s_setprio(1) for the second-dispatched half of the waves of a GEMM workgroup
+#endif
+#ifndef TG_ABL_BWD
+#define TG_ABL_BWD 0          // ablation builds only (never shipped): 1 = backward GEMM without its global X stores, 2 = without epilogue
+#endif
 #define TG_NEG_BIG (-3.0e38f)
 #define TG_COS_EPS 1e-8f
 
@@ -222,6 +231,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
+#if TG_YOUNG_PRIO && !defined(TG_SIM)
+    if (wave >= GE::NT / 128) __builtin_amdgcn_s_setprio(1);
+#endif
     int vt, kt, split;
     const bool band = a.band_step_end > 0;
     if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, band ? 1 : a.nsplit, vt, kt, split)) return;
@@ -279,13 +291,15 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     constexpr int NG_F = TgMmaShape<PR, GE, GA_F>::NG;
     constexpr int NSPREAD = (NG_F * 3) / 4 > 0 ? (NG_F * 3) / 4 : 1;
     constexpr int NITEM = GE::LB + RS + 1;
-    auto issue_next = [&](int step, u32x4* st, int i) {
+    // (step_m: the step whose M micro-block is fetched -- one step further ahead for the early half of the waves, see below;
+    //  step_b: the step whose S^T tile is copied into `st`; a negative step = nothing to fetch)
+    auto issue_next = [&](int step_m, int step_b, u32x4* st, int i) {
 #pragma unroll
         for (int k = 0; k < NITEM; ++k) {
             if ((k * NSPREAD) / NITEM != i) continue;
-            if (k < RS) load_m(step, k);
-            else if (k == RS) load_sh(step);
-            else tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)step, st + GE::A_CHUNKS, t, wave, k - RS - 1, GE::LB);
+            if (k < RS) { if (step_m >= 0) load_m(step_m, k); }
+            else if (k == RS) { if (step_m >= 0) load_sh(step_m); }
+            else if (step_b >= 0) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)step_b, st + GE::A_CHUNKS, t, wave, k - RS - 1, GE::LB);
         }
     };
     // (MASKED: edge tiles zero the spots >= V; interior tiles skip the 16 selects.  bf16x3: the arithmetic runs on pairs of
@@ -332,26 +346,40 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
         else store_stage_impl(st, std::true_type());
     };
 
+    // Phase-shifted operand staging.  The softmax staging of the next step (exp2, hi/lo split, transposed ds_write: VALU) is
+    // work of the same waves that issue the MFMAs; done by all eight waves at the same point of the step (after their MFMAs,
+    // before the barrier) it leaves the matrix pipes idle for its whole duration.  The two waves that share a SIMD therefore
+    // do it at OPPOSITE ends of the step: the EARLY half converts the block of step s+1 first thing in step s (its M loads run
+    // one step further ahead: issued during step s-1, so they also have a whole step to arrive), the LATE half after its MFMAs
+    // as before -- while one wave of a SIMD is in its VALU block the other one feeds the matrix pipe.  Same values, same
+    // order of arithmetic: results are bit-identical to the unshifted schedule.
+    // Measured at 30k x 1k x 10k (profiles/r02/run2-4): bf16 0.775 -> 0.675 ms with the YOUNGER half early (the older half
+    // early: 0.89); bf16x3 1.47 -> 1.58 either way, so the split-bf16 path keeps the unshifted schedule.  Slicing the staging
+    // between the MFMA groups of every wave instead (with or without vector-memory traffic in the staging slices) was 1.7x
+    // SLOWER (bf16x3 2.45 ms): VALU in the MFMA stream costs far more than its issue slots (profiles/r02/README.md).
+    constexpr int STAG = (TG_FWD_STAGGER >= 0) ? TG_FWD_STAGGER : ((PR::kId == 1) ? 2 : 0);
+    const bool early = (STAG == 1) ? (wave < GE::NT / 128) : ((STAG == 2) ? (wave >= GE::NT / 128) : false);
     if (s_begin < s_end) {
         tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)s_begin, lds + GE::A_CHUNKS, t, wave);
         load_stage(s_begin);
         store_stage(lds);
+        if (early && s_begin + 1 < s_end) load_stage(s_begin + 1);
         __syncthreads();
         for (int s = s_begin; s < s_end; ++s) {
             u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s - s_begin + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < s_end;
+            const int step_m = early ? ((s + 2) < s_end ? s + 2 : -1) : (more ? s + 1 : -1);    // M block to fetch during this step
+            if (early && more) store_stage(nxt);    // (`nxt` was last read in step s-1: every wave has passed that barrier)
             if (PR::NP == 2) {                      // next step's global loads / LDS-DMA trickle in between the MFMA groups
                                                     // (bf16x3: -2 %; slower for the 8-row micro-blocks of bf16, profiles/r01/run26)
-                tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [&](int i) { if (more) issue_next(s + 1, nxt, i); });
+                tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [&](int i) { issue_next(step_m, more ? s + 1 : -1, nxt, i); });
             } else {
-                if (more) {
-                    tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
-                    load_stage(s + 1);
-                }
+                if (more) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
+                if (step_m >= 0) load_stage(step_m);
                 tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [](int) {});
             }
-            if (more) store_stage(nxt);
+            if (!early && more) store_stage(nxt);
             __syncthreads();
         }
     }
@@ -503,6 +531,7 @@ struct TgFinalizeArgs {
     float* nbcoef;             // [2][Kp] -> d(loss)/d(W Ghat) = nbcoef0 * WG + nbcoef1 * WGhat
     const float* ctpart; int n_ctpart;   // per-spot sums of relu(D) (ct islands), or null
     float lambda_nb, lambda_ct; int T;
+    float* part_out;           // spot shards: [0] = this rank's part of the voxel score (sum_v cos / V_total), [1] = of the KL sum; or null
 };
 
 TG_DEV float tg_block_sum_1024(float x, float* red) {
@@ -626,8 +655,11 @@ TG_DEV void tg_loss_scalars(const TgFinalizeArgs& a, float* red) {
     if (t == 0) {
         const float nanv = __builtin_nanf("");
         float total = -a.lambda_g1 * gv;
-        if (a.lambda_g2 != 0.f) total -= a.lambda_g2 * vg;
-        if (a.has_density) total += a.lambda_d * klsum;
+        if (!a.part_out) {          // (spot shard: the terms that are sums over spots join the total in tg_merge_stats, once they
+                                    //  are global -- added in the same order on every rank, so the history is bit-identical everywhere)
+            if (a.lambda_g2 != 0.f) total -= a.lambda_g2 * vg;
+            if (a.has_density) total += a.lambda_d * klsum;
+        }
         for (int i = 0; i < TGH_NTERMS; ++i) a.hist[i] = nanv;
         a.hist[TGH_TOTAL] = total;
         a.hist[TGH_MAIN] = gv;
@@ -635,6 +667,7 @@ TG_DEV void tg_loss_scalars(const TgFinalizeArgs& a, float* red) {
         a.hist[TGH_KL] = a.has_density ? klsum : nanv;
         if (a.nbstat) { a.hist[TGH_NB] = nbv; a.hist[TGH_TOTAL] -= a.lambda_nb * nbv; }
         if (a.ctpart) { a.hist[TGH_CT] = isl; a.hist[TGH_TOTAL] += a.lambda_ct * isl; }
+        if (a.part_out) { a.part_out[0] = vg; a.part_out[1] = klsum; }
     }
 }
 
@@ -747,6 +780,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
+#if TG_YOUNG_PRIO && !defined(TG_SIM)
+    if (wave >= GE::NT / 128) __builtin_amdgcn_s_setprio(1);
+#endif
     int t_major, t_minor;
     if (!tg_tilemap(a.map, blockIdx.x, t_major, t_minor)) return;
     const int vt = a.map_major_is_cells ? t_minor : t_major, ct = a.ct_offset + (a.map_major_is_cells ? t_major : t_minor);
@@ -792,6 +828,13 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
     //                    (+ the entropy / L1 / L2 / filter row sums when FULL), reduced over the RC lanes of the row.  The M
     //                    segments of a whole pass are requested before the staging barrier (NIT loads in flight per lane);
     //                    the per-cell constants of the tile wait in the 4 KB of LDS behind the staging area.
+#if TG_ABL_BWD == 2 && !defined(TG_SIM)
+#pragma unroll
+    for (int i = 0; i < GE::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < GE::FN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+#endif
     constexpr int RC = GE::TM / 4;                                        // 16-byte columns of a staged row (one cell, TM spots)
     constexpr int CPP = (GE::LDS_BYTES / (GE::TM * 4) < GE::TN) ? GE::LDS_BYTES / (GE::TM * 4) : GE::TN;   // cells per pass
     constexpr int NPASS = GE::TN / CPP, FPP = GE::FN / NPASS;             // passes, cell fragments per wave and pass
@@ -842,7 +885,12 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
             const int cl = cell_of(pass, row), c = c0 + cl;
             const bool ok = c < a.C && v < a.Vp;
             const f32x4 x = stg[row * RC + (j ^ (row & 15))];
+#if TG_ABL_BWD == 1 && !defined(TG_SIM)
+            asm volatile("" ::"v"(x));
+            if (false) {
+#else
             if (ok) {
+#endif
                 if constexpr (PR::X16)
                     tg_st_stream<STREAM>(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
                 else
@@ -1189,6 +1237,7 @@ struct TgUpdateArgs {
                                                                            // new_scale = (max + ln Z) log2(e) are the forward's row constants
     int C, V, Vp, Vr, finalize;
     int c_begin;                                      // first cell of this launch (grid = number of cells)
+    int c_end;                                        // one past the last cell of this launch
     float lambda_r, lambda_l1, lambda_l2;
     float step_size, bc2_sqrt, beta1, beta2, eps;
     int fin_on;                                       // 1: the LAST workgroup of the grid computes the history scalars instead of a row
@@ -1485,7 +1534,7 @@ struct TgFilterArgs {
     float* fgate;                        // [C] sigmoid(F)
     float* fsum;                         // [2]: fsum, scratch
     const float* rowq;                   // [TGP1_N][C]
-    const float* d; int V;               // density prior (for sum d)
+    const float* dsum;                   // [1] sum of the density prior over ALL spots (set-up; all-reduced over spot shards)
     float* hist;
     int C, do_update, has_density;
     float lambda_d, lambda_count, lambda_f_reg, target_count;
@@ -1497,9 +1546,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel(TgFilterArgs a) {
     const int t = threadIdx.x;
     if (a.do_update) {
         const float fsum = a.fsum[0];
-        float ds = 0.f;
-        if (a.has_density) for (int v = t; v < a.V; v += 1024) ds += a.d[v];
-        const float dsum = tg_block_sum_1024(ds, red);
+        const float dsum = a.has_density ? a.dsum[0] : 0.f;
         float fr = 0.f;
         for (int c = t; c < a.C; c += 1024) { const float f = a.fgate[c]; fr += f - f * f; }
         const float freg = tg_block_sum_1024(fr, red);
@@ -1534,22 +1581,52 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel(TgFilterArgs a) {
     if (t == 0) a.fsum[0] = fsum_new;
 }
 
-// merge (max, sum exp) partials over `nparts` -> rshift = max, rinvz = 1/Z ; optional raw output
+// merge (max, sum exp) partials over `nparts` -> rshift = max, rinvz = 1/Z ; optional raw output.
+// Spot shards (nparts = ranks, `part` = the all-gathered blocks of `stride` floats: [2][C] pairs + TG_PAIR_TAIL history
+// scalars): thread 0 of block 0 also turns this rank's history row into the GLOBAL one -- the terms that are sums over spots
+// (voxel score, KL) arrive as per-rank partials in the tail of every block and are added in rank order (deterministic).
+#define TG_PAIR_TAIL 64        // floats appended to the [2][C] statistics block of a rank: [0] = vg partial, [1] = KL partial
 struct TgMergeArgs {
-    const float* part;         // [nparts][2][C]
+    const float* part;         // [nparts] blocks of `stride` floats: max at [c], sum exp at [C + c]
     int nparts, C;
+    size_t stride;
     float* rshift; float* rinvz;       // final (may be null when only the local pair is wanted)
     float* pair_out;           // [2][C] local (max, Z) for the cross-GPU exchange, or null
     const float* fgate; float* rmul; float* rscale;   // forward row constants: f_c / Z_c and (max + ln Z - ln f_c) * log2(e)
+    float* hist; int rank;     // spot shards: history row to complete with the global spot sums (or null), this rank's index
+    float lambda_g2, lambda_d; int has_density;
 };
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
     const int c = blockIdx.x * 256 + threadIdx.x;
+    if (a.hist && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float* tail = a.part + 2 * (size_t)a.C;
+        float vg = 0.f, kl = 0.f;
+        for (int p = 0; p < a.nparts; ++p) { vg += tail[p * a.stride]; kl += tail[p * a.stride + 1]; }
+        float total = a.hist[TGH_TOTAL];                 // so far: every term that is not a sum over spots (tg_loss_scalars)
+        if (a.lambda_g2 != 0.f) { a.hist[TGH_VG] = vg; total -= a.lambda_g2 * vg; }
+        if (a.has_density) { a.hist[TGH_KL] = kl; total += a.lambda_d * kl; }
+        a.hist[TGH_TOTAL] = total;
+    }
     if (c >= a.C) return;
+    float pm[8], pz[8];                                    // all loads of a cell in flight at once (<= 8 parts per trip)
     float mx = TG_NEG_BIG;
-    for (int p = 0; p < a.nparts; ++p) mx = tg_fmax(mx, a.part[((size_t)p * 2 + 0) * a.C + c]);
+    for (int p0 = 0; p0 < a.nparts; p0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pm[q] = (p0 + q < a.nparts) ? a.part[(size_t)(p0 + q) * a.stride + c] : TG_NEG_BIG;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mx = tg_fmax(mx, pm[q]);
+    }
     float z = 0.f;
-    for (int p = 0; p < a.nparts; ++p)
-        z += a.part[((size_t)p * 2 + 1) * a.C + c] * tg_exp(a.part[((size_t)p * 2 + 0) * a.C + c] - mx);
+    for (int p0 = 0; p0 < a.nparts; p0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool on = p0 + q < a.nparts;
+            pm[q] = on ? a.part[(size_t)(p0 + q) * a.stride + c] : TG_NEG_BIG;
+            pz[q] = on ? a.part[(size_t)(p0 + q) * a.stride + a.C + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (p0 + q < a.nparts) z += pz[q] * tg_exp(pm[q] - mx);
+    }
     if (a.pair_out) { a.pair_out[c] = mx; a.pair_out[a.C + c] = z; }
     if (a.rshift) {
         const float iz = 1.f / z;
@@ -1731,6 +1808,15 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_g(const float* G, int V, int K, int
     }
     __syncthreads();
     if (t < TG_RB && vbeg + t < Vr) vnorm2[vbeg + t] = red[t] + red[TG_RB + t] + red[2 * TG_RB + t] + red[3 * TG_RB + t];
+}
+
+// out[0] = sum_i x[i]  (one block of 1024 threads, fixed order): the density prior's total, used by the filter gradient (:512-515)
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_vec_sum(const float* x, int n, float* out) {
+    TG_LDS_DECL;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+    const float tot = tg_block_sum_1024(s, (float*)tg_lds);
+    if (threadIdx.x == 0) out[0] = tot;
 }
 
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_colsum_parts(const float* part, int nparts, int n, float* out, float scale) {

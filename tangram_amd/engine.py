@@ -38,7 +38,7 @@ class HipMapperEngine:
     """State + workspace of one mapping problem (or one spot-shard of it) on one GPU."""
 
     def __init__(self, S, G, M0, d=None, d_source=None, F0=None, *, mode="mapper", device="cuda:0",
-                 precision="bf16x3", lambdas=None, n_spots_total=None, fwd_splits=0, tile_size=0, pipeline_bands=0,
+                 precision="bf16x3", lambdas=None, n_spots_total=None, n_ranks=0, fwd_splits=0, tile_size=0, pipeline_bands=0,
                  target_count=0.0, betas=(0.9, 0.999), eps=1e-8,
                  voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
         self.device = torch.device(device)
@@ -71,6 +71,7 @@ class HipMapperEngine:
         cfg.precision = _capi.PRECISIONS[precision]
         cfg.n_cells, cfg.n_genes, cfg.n_spots = self.C, self.K, self.V
         cfg.n_spots_total = int(n_spots_total or self.V)
+        cfg.n_ranks = int(n_ranks)
         cfg.has_density = int(d is not None)
         cfg.has_d_source = int(d_source is not None)
         cfg.fwd_splits = int(fwd_splits)
@@ -189,17 +190,16 @@ class HipMapperEngine:
         hp = history.data_ptr() if history is not None else None
         self._call(self._lib.tg_mapper_step, self._h, int(n_steps), float(lr), hp, int(first_row), tensors=(history,))
 
-    def phase(self, phase, lr=0.0, history_row=None, gathered=None, nranks=0):
-        hp = history_row.data_ptr() if history_row is not None else None
-        gp = gathered.data_ptr() if gathered is not None else None
-        self._call(self._lib.tg_mapper_phase, self._h, int(phase), float(lr), hp, gp, int(nranks), tensors=(history_row, gathered))
+    def attach_comm(self, comm_handle):
+        """Spot shard: bind a `tg_comm` (tangram_amd.sharded builds it); collective -- performs the set-up exchanges."""
+        self._call(self._lib.tg_mapper_attach_comm, self._h, comm_handle)
 
-    def exchange_buffer(self, which):
-        """A float32 torch view (no copy) of one of the cross-GPU exchange vectors inside the workspace."""
-        p, n = ct.c_void_p(), ct.c_size_t()
-        self._call(self._lib.tg_mapper_exchange_buffer, self._h, int(which), ct.byref(p), ct.byref(n))
-        off = p.value - self.workspace.data_ptr()
-        return self.workspace[off:off + 4 * n.value].view(torch.float32)
+    def workspace_view(self, ptr, n_floats):
+        """float32 torch view (no copy) of `n_floats` at device address `ptr` inside this handle's workspace."""
+        off = int(ptr) - self.workspace.data_ptr()
+        if off < 0 or off + 4 * n_floats > self.workspace.numel():
+            raise ValueError("pointer outside the workspace")
+        return self.workspace[off:off + 4 * n_floats].view(torch.float32)
 
     def result(self, with_filter=False):
         P = torch.empty((self.C, self.V), dtype=torch.float32, device=self.device)

@@ -11,8 +11,17 @@ history keys as the reference, so that `tangram.mapping_utils.map_cells_to_space
 All arithmetic of the training loop runs in hand-written HIP kernels (tangram_amd/csrc); this file
 only prepares inputs, owns the handle and formats the history.  There is no CPU path.
 
-Extra keyword (not in the reference): `gemm_precision` in {"bf16x3" (default, fp32-parity split-bf16
-matrix-core products), "fp32" (exact fp32 MFMA), "bf16"}.
+Extra keywords (not in the reference): `gemm_precision` in {"bf16x3" (default, fp32-parity split-bf16
+matrix-core products), "fp32" (exact fp32 MFMA), "bf16"}; `distributed` / `group` -- multi-GPU:
+
+    torchrun --nproc-per-node 8 script.py        # one process per GPU, torch.distributed.init_process_group("nccl")
+    ad_map = tg.map_cells_to_space(adata_sc, adata_sp, device=f"cuda:{LOCAL_RANK}", ...)    # same call on every rank
+
+With a process group of more than one rank initialised, `Mapper` / `MapperConstrained` shard the SPOTS over the ranks
+(tangram_amd/sharded.py: each rank trains its block of columns of M, three small RCCL exchanges per iteration) and every
+rank returns the full mapping matrix and the same training history.  `distributed=False` keeps a mapper on its own GPU,
+`distributed=True` insists on sharding.  The initial logits are drawn exactly like the reference does on every rank (same
+seed, same full C x V draw) and then sliced, so a sharded run follows the single-GPU trajectory up to summation order.
 """
 from __future__ import annotations
 
@@ -42,6 +51,26 @@ def _to_numpy_f32(x):
     if hasattr(x, "to_numpy"):            # pandas Series (density priors come from adata.obs)
         x = x.to_numpy()
     return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def _shard_context(distributed, group, blockers):
+    """(sharded?, world, rank): shard over the process group iff asked to, or -- `distributed=None` -- whenever
+    torch.distributed is initialised with more than one rank and nothing in `blockers` (spatial terms) forbids it."""
+    import torch.distributed as dist
+    live = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    if distributed is False or (distributed is None and world <= 1):
+        return False, world, rank
+    if distributed and not live:
+        raise RuntimeError("distributed=True needs an initialised torch.distributed process group (one rank per GPU)")
+    if blockers:
+        if distributed:
+            raise NotImplementedError("spot sharding is not available with " + ", ".join(blockers) +
+                                      " (the spatial terms need the whole spot graph on one GPU)")
+        logging.warning("tangram_amd: %s -> every rank trains the whole problem on its own GPU (no spot sharding)", ", ".join(blockers))
+        return False, world, rank
+    return True, world, rank
 
 
 def _print_terms(names_vals):
@@ -81,6 +110,8 @@ class Mapper:
         *,
         gemm_precision="bf16x3",
         M_init=None,
+        distributed=None,
+        group=None,
     ):
         if adata_map is not None:
             raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :151-153)")
@@ -117,10 +148,21 @@ class Mapper:
                        lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2,
                        lambda_neighborhood_g1=lambda_neighborhood_g1, lambda_ct_islands=lambda_ct_islands,
                        lambda_getis_ord=lambda_getis_ord, lambda_moran=lambda_moran, lambda_geary=lambda_geary)
-        self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
-                                       mode="mapper", device=self.device, precision=gemm_precision, lambdas=lambdas,
-                                       voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
-                                       ct_encode=_to_numpy_f32(ct_encode), spatial_weights=spatial_weights)
+        blockers = [n for n, on in (("lambda_neighborhood_g1", lambda_neighborhood_g1), ("lambda_ct_islands", lambda_ct_islands),
+                                    ("lambda_getis_ord", lambda_getis_ord), ("lambda_moran", lambda_moran),
+                                    ("lambda_geary", lambda_geary)) if on]
+        sharded, self._world, self._rank = _shard_context(distributed, group, blockers)
+        self._sharded = None
+        if sharded:
+            from .sharded import make_sharded
+            self._sharded = make_sharded(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
+                                         device=self.device, precision=gemm_precision, lambdas=lambdas, group=group)
+            self._engine = self._sharded.eng
+        else:
+            self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
+                                           mode="mapper", device=self.device, precision=gemm_precision, lambdas=lambdas,
+                                           voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
+                                           ct_encode=_to_numpy_f32(ct_encode), spatial_weights=spatial_weights)
 
     # ------------------------------------------------------------------------------------------------
     def _history_dict(self, hist):
@@ -143,6 +185,10 @@ class Mapper:
         if print_each:
             logging.info(f"Printing scores every {print_each} epochs.")
         eng = self._engine
+        if self._sharded is not None and val_each is not None:
+            raise NotImplementedError("val_each is not available on a spot-sharded (multi-GPU) run; pass distributed=False")
+        run = self._sharded.run if self._sharded is not None else eng.step      # sharded: kernels + exchanges in one C call
+        quiet = self._rank != 0                              # a sharded run prints its scores once, not once per rank
         hist = eng.new_history(max(int(num_epochs), 1))
         val_rows = []
         t = 0
@@ -153,14 +199,15 @@ class Mapper:
             if val_each is not None:
                 stops.append(t if t % val_each == 0 else (t // val_each + 1) * val_each)
             n = min(stops) - t + 1
-            eng.step(n, learning_rate, hist, t)
+            run(n, learning_rate, hist, t)
             t += n
-            if print_each and (t - 1) % print_each == 0:
+            if print_each and (t - 1) % print_each == 0 and not (self._sharded is not None and quiet):
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
             if val_each is not None and (t - 1) % val_each == 0:
                 val_rows.append(eng.validate())              # reference :398-403: after optimizer.step() of epoch t-1
-        output = eng.result().detach().cpu().numpy()         # reference :406-408
+        P_dev = self._sharded.result_full() if self._sharded is not None else eng.result()
+        output = P_dev.detach().cpu().numpy()                # reference :406-408
         history = self._history_dict(hist[:num_epochs])
         for row in val_rows:
             for k, x in zip(_VAL_KEYS, row):
@@ -170,11 +217,14 @@ class Mapper:
     # extras -----------------------------------------------------------------------------------------
     def release(self):
         """Free the device memory of this mapper (logits, Adam moments, X, workspace); the object is unusable afterwards."""
-        self._engine.release()
+        (self._sharded or self._engine).release()
 
     def project_genes_device(self, S_all=None):
         """softmax(M)^T S on the device (what mapping_utils.py:402 and utils.py:368 compute in NumPy on the host);
-        `S_all` [n_cells, n_genes_any]: project another gene set (project_genes), default: the training genes."""
+        `S_all` [n_cells, n_genes_any]: project another gene set (project_genes), default: the training genes.
+        On a sharded run every rank projects onto its spots and the row blocks are gathered: [V_total, K] everywhere."""
+        if self._sharded is not None:
+            return self._sharded.project_full(S_all)
         return self._engine.project() if S_all is None else self._engine.project_genes(S_all)
 
 
@@ -206,6 +256,8 @@ class MapperConstrained:
         gemm_precision="bf16x3",
         M_init=None,
         F_init=None,
+        distributed=None,
+        group=None,
     ):
         if adata_map is not None:
             raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :476-478)")
@@ -226,8 +278,16 @@ class MapperConstrained:
             F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)                 # :490
         lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
                        lambda_r=lambda_r, lambda_count=lambda_count, lambda_f_reg=lambda_f_reg)
-        self._engine = HipMapperEngine(S, G, M_init, d=d, F0=F_init, mode="constrained", device=self.device,
-                                       precision=gemm_precision, lambdas=lambdas, target_count=float(self.target_count))
+        sharded, self._world, self._rank = _shard_context(distributed, group, [])
+        self._sharded = None
+        if sharded:
+            from .sharded import make_sharded
+            self._sharded = make_sharded(S, G, M_init, d=d, F0=F_init, mode="constrained", device=self.device,
+                                         precision=gemm_precision, lambdas=lambdas, target_count=float(self.target_count), group=group)
+            self._engine = self._sharded.eng
+        else:
+            self._engine = HipMapperEngine(S, G, M_init, d=d, F0=F_init, mode="constrained", device=self.device,
+                                           precision=gemm_precision, lambdas=lambdas, target_count=float(self.target_count))
 
     def train(self, num_epochs, learning_rate=0.1, print_each=100):
         """Returns (mapping matrix [C, V], filter [C], training_history) like the reference (:589-639).
@@ -236,6 +296,7 @@ class MapperConstrained:
         if self.random_state:
             torch.manual_seed(seed=self.random_state)
         eng = self._engine
+        run = self._sharded.run if self._sharded is not None else eng.step
         hist = eng.new_history(max(int(num_epochs), 1))
         t = 0
         while t < num_epochs:
@@ -244,12 +305,12 @@ class MapperConstrained:
                 n = min(nxt, num_epochs - 1) - t + 1
             else:
                 n = num_epochs - t
-            eng.step(n, learning_rate, hist, t)
+            run(n, learning_rate, hist, t)
             t += n
-            if print_each and (t - 1) % print_each == 0:
+            if print_each and (t - 1) % print_each == 0 and not (self._sharded is not None and self._rank != 0):
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES_CONSTRAINED])
-        P, F = eng.result(with_filter=True)
+        P, F = self._sharded.result_full(with_filter=True) if self._sharded is not None else eng.result(with_filter=True)
         h = hist[:num_epochs].detach().cpu().numpy()
         cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_COUNT, _capi.H_FREG]
         active = [True, True, bool(self.lambda_g2), bool(self.target_density_enabled and self.lambda_d), bool(self.lambda_r), True, True]
@@ -261,9 +322,11 @@ class MapperConstrained:
 
     def release(self):
         """Free the device memory of this mapper; the object is unusable afterwards."""
-        self._engine.release()
+        (self._sharded or self._engine).release()
 
     def project_genes_device(self, S_all=None, unfiltered=True):
         """Like Mapper.project_genes_device; `unfiltered`: softmax(M) alone, as `adata_map.X` holds it (:637), else times
         the learned filter.  Without `S_all`: the (filtered) training-time projection."""
+        if self._sharded is not None:
+            return self._sharded.project_full(S_all, unfiltered=unfiltered)
         return self._engine.project() if S_all is None else self._engine.project_genes(S_all, unfiltered=unfiltered)

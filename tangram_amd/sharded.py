@@ -1,15 +1,27 @@
-"""Spot-sharded multi-GPU driver: one process per GPU (torch.distributed, backend "nccl" = RCCL over
-xGMI), each rank owns a contiguous block of spots: M[:, V_g], its Adam moments, G[V_g, :], d[V_g].
-S is replicated.  Per iteration exactly three small vectors cross GPUs:
+"""Spot-sharded multi-GPU driver: one process per GPU (torch.distributed launches the ranks; backend "nccl" = RCCL over
+xGMI), each rank owns a contiguous block of spots: M[:, V_g], its Adam moments, G[V_g, :], d[V_g].  S (and the
+constrained-mode filter F) are replicated.  Per iteration exactly three small vectors cross GPUs:
 
     E2  per-gene cosine statistics [2][Kp]            all-reduce(sum)     after the forward GEMM
-    E3  per-cell softmax-backward row dots [np][C]    all-reduce(sum)     after the first backward pass
-    E1  per-cell (max, sum exp) of the new logits     all-gather + merge  after the Adam update
+    E3  per-cell softmax-backward row dots [np][C]    all-reduce(sum)     after the backward GEMM
+    E1  per-cell (max, sum exp) of the new logits     all-gather + merge  after the Adam update (+ 2 history scalars per rank)
 
-The gradient of M itself is column-sharded exactly like M and never leaves its GPU.  The reference has
-no distributed code at all; this module is new capability, not a translation.
+The gradient of M itself is column-sharded exactly like M and never leaves its GPU.  The whole step -- kernels AND the three
+exchanges -- is issued by the C library inside `tg_mapper_step` (include/tangram_hip.h: tg_comm, tg_mapper_attach_comm):
+
+  * transport "rccl": the library binds librccl.so itself and calls ncclAllReduce / ncclAllGather on the handle's stream, between
+    its own kernels: no Python, no second stream and no event between a kernel and the collective that consumes its output.
+    The communicator is bootstrapped with one 128-byte broadcast over torch.distributed.
+  * transport "callbacks": the library calls back into this module, which runs the collective through any object with
+    `all_reduce(t)` / `all_gather_into_tensor(out, t)` (torch.distributed with gloo in the CPU tests, an in-process communicator
+    for several shards of one GPU in the GPU tests).
+
+The reference has no distributed code at all; this module is new capability, not a translation.
 """
 from __future__ import annotations
+
+import ctypes as ct
+import os
 
 import numpy as np
 import torch
@@ -20,7 +32,7 @@ from .engine import HipMapperEngine
 
 
 class DistComm:
-    """The collectives of the sharded step on a torch.distributed process group (RCCL on GPUs)."""
+    """The collectives of the sharded step on a torch.distributed process group."""
 
     def __init__(self, group=None):
         self.group = group
@@ -36,6 +48,9 @@ class DistComm:
     def all_gather(self, outs, t):
         dist.all_gather(outs, t, group=self.group)
 
+    def broadcast(self, t, src=0):
+        dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+
 
 def shard_bounds(n, world, rank):
     """Contiguous, balanced partition of range(n) into `world` blocks."""
@@ -44,84 +59,145 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rccl_library_path():
+    """The librccl.so PyTorch-ROCm ships (the one torch.distributed's "nccl" backend uses), else the ROCm installation's."""
+    for p in (os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so"):
+        if os.path.exists(p):
+            return p
+    return None
+
+
 class ShardedMapperEngine:
-    def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, *, n_spots_total, device, precision="bf16x3",
-                 lambdas=None, group=None, fwd_splits=0, tile_size=0, comm=None):
+    def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, F0=None, *, n_spots_total, device, mode="mapper",
+                 precision="bf16x3", lambdas=None, target_count=0.0, group=None, fwd_splits=0, tile_size=0, comm=None,
+                 transport="auto"):
         # `comm`: anything with world, rank, all_reduce, all_gather_into_tensor, all_gather (tests drive several shards of one
         # GPU through an in-process communicator); default: the torch.distributed group
-        self.comm = comm if comm is not None else DistComm(group)
+        self.pycomm = comm if comm is not None else DistComm(group)
         self.group = group
-        self.world = self.comm.world
-        self.rank = self.comm.rank
+        self.world = self.pycomm.world
+        self.rank = self.pycomm.rank
         self.lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0)
         self.lam.update(lambdas or {})
-        self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, device=device,
-                                   precision=precision, lambdas=self.lam, n_spots_total=n_spots_total,
-                                   fwd_splits=fwd_splits, tile_size=tile_size)
+        self.mode = mode
+        self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, F0=F0, mode=mode, device=device,
+                                   precision=precision, lambdas=self.lam, n_spots_total=n_spots_total, n_ranks=self.world,
+                                   fwd_splits=fwd_splits, tile_size=tile_size, target_count=target_count)
         self.has_density = d_local is not None
-        e = self.eng
-        self.x_gene = e.exchange_buffer(_capi.X_GENESTAT)
-        self.x_rowq = e.exchange_buffer(_capi.X_ROWQ)
-        self.x_pair = e.exchange_buffer(_capi.X_ROWPAIR)
-        self.gathered = torch.empty(self.world * self.x_pair.numel(), dtype=torch.float32, device=e.device)
-        # set-up exchange: |G_k|^2 over all spots, then the softmax statistics of the initial logits
-        self.comm.all_reduce(e.exchange_buffer(_capi.X_GNORM2))
-        e.phase(0)
-        self._exchange_row_stats()
+        self.n_spots_total = int(n_spots_total)
+        lib = self.eng._lib
+        if transport == "auto":
+            is_nccl = comm is None and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+            transport = "rccl" if (is_nccl and not _capi.is_emulated() and self.eng.device.type == "cuda") else "callbacks"
+        self.transport = transport
+        self._error = None
+        handle = ct.c_void_p()
+        if transport == "rccl":
+            uid = torch.zeros(128, dtype=torch.uint8)
+            path = rccl_library_path()
+            cpath = path.encode() if path else None
+            if self.rank == 0:
+                buf = ct.create_string_buffer(128)
+                _capi.check(lib.tg_comm_rccl_unique_id(cpath, buf))
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            uid = uid.to(self.eng.device)                # the nccl backend broadcasts device tensors
+            self.pycomm.broadcast(uid, 0) if hasattr(self.pycomm, "broadcast") else dist.broadcast(uid, 0, group=group)
+            raw = bytes(uid.cpu().numpy().tobytes())
+            with torch.cuda.device(self.eng.device):
+                _capi.check(lib.tg_comm_create_rccl(cpath, raw, self.world, self.rank, ct.byref(handle)))
+        elif transport == "callbacks":
+            self._cb_ar = _capi.ALL_REDUCE_FN(self._cb_all_reduce)       # (kept alive: the C side stores the function pointers)
+            self._cb_ag = _capi.ALL_GATHER_FN(self._cb_all_gather)
+            _capi.check(lib.tg_comm_create_callbacks(self.world, self.rank, self._cb_ar, self._cb_ag, None, ct.byref(handle)))
+        else:
+            raise ValueError("transport must be 'auto', 'rccl' or 'callbacks'")
+        self._comm = handle
+        self._attach()
 
-    def _exchange_row_stats(self):
-        self.comm.all_gather_into_tensor(self.gathered, self.x_pair)
-        self.eng.phase(4, gathered=self.gathered, nranks=self.world)
+    # -- callback transport -----------------------------------------------------------------------------------------------
+    def _cb_all_reduce(self, ctx, buf, n, stream):
+        try:
+            self.pycomm.all_reduce(self.eng.workspace_view(buf, n))
+            return 0
+        except BaseException as e:       # noqa: BLE001 -- reported by the caller of tg_mapper_step, never raised through C
+            self._error = e
+            return 1
+
+    def _cb_all_gather(self, ctx, send, recv, n, stream):
+        try:
+            self.pycomm.all_gather_into_tensor(self.eng.workspace_view(recv, n * self.world), self.eng.workspace_view(send, n))
+            return 0
+        except BaseException as e:       # noqa: BLE001
+            self._error = e
+            return 1
+
+    def _guard(self, fn, *args, **kw):
+        try:
+            return fn(*args, **kw)
+        except Exception:
+            if self._error is not None:
+                err, self._error = self._error, None
+                raise err
+            raise
+
+    def _attach(self):
+        self._guard(self.eng.attach_comm, self._comm)
+
+    # -- the hot path -----------------------------------------------------------------------------------------------------
+    def run(self, n_steps, lr, history=None, first_row=0):
+        """`n_steps` sharded iterations in ONE call of the C library; the history rows are global (identical on every rank)."""
+        self._guard(self.eng.step, n_steps, lr, history, first_row)
 
     def step(self, lr, history_row=None):
-        e = self.eng
-        e.phase(1)
-        self.comm.all_reduce(self.x_gene)
-        e.phase(2, history_row=history_row)
-        self.comm.all_reduce(self.x_rowq)
-        e.phase(3, lr=lr, history_row=history_row)
-        self._exchange_row_stats()
-
-    def run(self, n_steps, lr, history=None, first_row=0):
-        for i in range(n_steps):
-            self.step(lr, history[first_row + i] if history is not None else None)
+        hist = history_row.view(1, -1) if history_row is not None else None
+        self.run(1, lr, hist, 0)
 
     def finalize_history(self, history):
-        """Terms that are sums over spots were accumulated per shard: reduce them and recompose the total."""
-        h = history.clone()
-        add_cols = [_capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_L1, _capi.H_L2]
-        part = torch.nan_to_num(h[:, add_cols], nan=0.0)
-        self.comm.all_reduce(part)
-        lam = self.lam
-        total = -lam["lambda_g1"] * h[:, _capi.H_MAIN]
-        for col, key, sign in ((_capi.H_VG, "lambda_g2", -1.0), (_capi.H_KL, "lambda_d", 1.0),
-                               (_capi.H_ENTROPY, "lambda_r", 1.0), (_capi.H_L1, "lambda_l1", 1.0),
-                               (_capi.H_L2, "lambda_l2", 1.0)):
-            j = add_cols.index(col)
-            active = lam[key] != 0 and (col != _capi.H_KL or self.has_density)
-            if active:
-                h[:, col] = part[:, j]
-                total = total + sign * lam[key] * part[:, j]
-        h[:, _capi.H_TOTAL] = total
-        return h
+        """Kept for callers of the earlier API: the rows written by `run` are already the global history."""
+        return history
 
-    def result_full(self):
-        """All-gather the column blocks of softmax(M) -> [C, V_total] on every rank."""
-        P_local = self.eng.result()
-        sizes = [shard_bounds(self.eng.cfg.n_spots_total, self.world, r) for r in range(self.world)]
-        widths = [b - a for a, b in sizes]
+    def result_full(self, with_filter=False):
+        """All-gather the column blocks of softmax(M) -> [C, V_total] on every rank (+ the replicated filter)."""
+        if with_filter:
+            P_local, F = self.eng.result(with_filter=True)
+        else:
+            P_local, F = self.eng.result(), None
+        P = self._gather_columns(P_local)
+        return (P, F) if with_filter else P
+
+    def project_full(self, S_all=None, unfiltered=True):
+        """softmax(M)^T S for every spot: each rank projects onto its own spots, the row blocks are gathered -> [V_total, K]."""
+        Gh = self.eng.project() if S_all is None else self.eng.project_genes(S_all, unfiltered=unfiltered)
+        return self._gather_columns(Gh.t().contiguous()).t().contiguous()
+
+    def _gather_columns(self, X_local):
+        widths = [b - a for a, b in (shard_bounds(self.n_spots_total, self.world, r) for r in range(self.world))]
         wmax = max(widths)
-        pad = torch.zeros((P_local.shape[0], wmax), dtype=torch.float32, device=P_local.device)
-        pad[:, :P_local.shape[1]] = P_local
+        pad = torch.zeros((X_local.shape[0], wmax), dtype=torch.float32, device=X_local.device)
+        pad[:, :X_local.shape[1]] = X_local
         out = [torch.empty_like(pad) for _ in range(self.world)]
-        self.comm.all_gather(out, pad)
+        self.pycomm.all_gather(out, pad)
         return torch.cat([o[:, :w] for o, w in zip(out, widths)], dim=1)
 
+    def release(self):
+        if getattr(self, "eng", None) is not None:
+            self.eng.release()
+        if getattr(self, "_comm", None):
+            self.eng._lib.tg_comm_destroy(self._comm)
+            self._comm = None
 
-def make_sharded(S, G, M0, d=None, d_source=None, *, device, precision="bf16x3", lambdas=None, group=None, fwd_splits=0, comm=None):
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapper", precision="bf16x3", lambdas=None,
+                 target_count=0.0, group=None, fwd_splits=0, comm=None, transport="auto"):
     """Slice full problem arrays (identical on every rank) into this rank's spot block."""
-    comm = comm if comm is not None else DistComm(group)
-    world, rank = comm.world, comm.rank
+    pc = comm if comm is not None else DistComm(group)
+    world, rank = pc.world, pc.rank
     V = G.shape[0]
     lo, hi = shard_bounds(V, world, rank)
     if hi - lo < 1:
@@ -133,5 +209,6 @@ def make_sharded(S, G, M0, d=None, d_source=None, *, device, precision="bf16x3",
     else:
         M_l = M_l.contiguous()
     d_l = None if d is None else d[lo:hi]
-    return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, n_spots_total=V, device=device, precision=precision,
-                               lambdas=lambdas, group=group, fwd_splits=fwd_splits, comm=comm)
+    return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, F0, n_spots_total=V, device=device, mode=mode, precision=precision,
+                               lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, comm=comm,
+                               transport=transport)

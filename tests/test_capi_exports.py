@@ -26,7 +26,7 @@ def test_hip_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     lib.tg_abi_version.restype = ctypes.c_int
-    assert lib.tg_abi_version() == 1
+    assert lib.tg_abi_version() == 2
 
 
 def test_argument_errors_are_reported_not_aborted():
@@ -36,7 +36,7 @@ def test_argument_errors_are_reported_not_aborted():
     cfg = _capi.TgConfig()
     sizes = _capi.TgSizes()
     assert lib.tg_query_sizes(ctypes.byref(cfg), ctypes.byref(sizes)) == -1          # abi_version 0
-    cfg.abi_version = 1
+    cfg.abi_version = _capi.TG_ABI_VERSION
     cfg.n_cells, cfg.n_genes, cfg.n_spots = 10, 5, 7
     cfg.lambda_g1 = 0.0
     assert lib.tg_query_sizes(ctypes.byref(cfg), ctypes.byref(sizes)) == -1          # lambda_g1 cannot be 0

@@ -18,7 +18,7 @@ def test_native_library_is_the_one_running():
     from tangram_amd import _capi
     assert torch.cuda.is_available()
     assert not _capi.is_emulated()
-    assert _capi.lib().tg_abi_version() == 1
+    assert _capi.lib().tg_abi_version() == 2
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
@@ -307,7 +307,7 @@ def test_concurrent_mappings_bit_identical():
 
 @pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "bf16x3"), (4, "bf16x3")])
 def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
-    """The multi-GPU driver (tangram_amd.sharded: phases + three exchanges per step) with `world` shards of one problem as
+    """The multi-GPU driver (tangram_amd.sharded; the C library issues kernels + three exchanges per step) with `world` shards of one problem as
     threads on ONE GPU (tests/local_comm.py instead of RCCL): same history and mapping as the unsharded engine and the fp64
     oracle, with regularisers and a d_source prior, ragged shard widths."""
     from oracle import tangram_oracle as orc
@@ -327,7 +327,7 @@ def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
         sh = make_sharded(data["S"], data["G"], M0, d=data["d"], d_source=ds, device=DEV, precision=precision, lambdas=lam, comm=comm)
         hist = sh.eng.new_history(n)
         sh.run(n, 0.1, hist)
-        return sh.finalize_history(hist).cpu().numpy(), sh.result_full().cpu().numpy()
+        return hist.cpu().numpy(), sh.result_full().cpu().numpy()          # (the rows `run` writes are the global history)
 
     res = run_ranks(world, rank_fn)
     e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], d_source=ds, device=DEV, precision=precision, lambdas=lam)
@@ -342,6 +342,50 @@ def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
         np.testing.assert_allclose(P, P1, atol=2e-6)
         np.testing.assert_allclose(hist[:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
         assert np.abs(P - Po).max() < 2e-5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_constrained_spot_shards_match_single_engine(world):
+    """MapperConstrained on spot shards (the filter F is replicated; its gradient comes from the all-reduced row sums, the
+    density prior's total from the set-up exchange): same history, mapping, filter and projection as the unsharded engine
+    and the fp64 oracle."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import make_sharded
+    from tangram_amd import _capi
+    from tests.local_comm import run_ranks
+    C, K, V = 350, 40, 777
+    data = orc.make_synthetic(C, K, V, seed=17)
+    M0, F0 = orc.reference_init_MF_constrained(C, V, 23)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.6, lambda_r=1e-3, lambda_count=0.7, lambda_f_reg=1.5)
+    n, tc = 6, 120.0
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], F0=F0, mode="constrained", device=DEV, precision="bf16x3",
+                          lambdas=lam, target_count=tc, comm=comm)
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist)
+        P, F = sh.result_full(with_filter=True)
+        return hist.cpu().numpy(), P.cpu().numpy(), F.cpu().numpy(), sh.project_full().cpu().numpy()
+
+    res = run_ranks(world, rank_fn)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], F0=F0, mode="constrained", device=DEV, precision="bf16x3",
+                        lambdas=lam, target_count=tc)
+    h1 = e.new_history(n)
+    e.step(n, 0.1, h1)
+    P1, F1 = e.result(with_filter=True)
+    h1, P1, F1, G1 = h1.cpu().numpy(), P1.cpu().numpy(), F1.cpu().numpy(), e.project().cpu().numpy()
+    o = orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0, F0=F0, target_count=tc, dtype=np.float64, **lam)
+    Po, Fo, ho = o.train(n, 0.1)
+    cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_COUNT, _capi.H_FREG]
+    for hist, P, F, G in res:
+        np.testing.assert_allclose(hist, res[0][0], rtol=3e-7, atol=0, equal_nan=True)    # every rank holds the same global history
+        np.testing.assert_allclose(hist[:, cols], h1[:, cols], atol=5e-6, rtol=2e-6)
+        np.testing.assert_allclose(P, P1, atol=2e-6)
+        np.testing.assert_allclose(F, F1, atol=2e-6)
+        np.testing.assert_allclose(G, G1, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(hist[:, _capi.H_TOTAL], np.array(ho["total_loss"], dtype=np.float64), atol=2e-5, rtol=1e-5)
+        assert np.abs(P - Po).max() < 2e-5 and np.abs(F - Fo).max() < 2e-5
 
 
 @pytest.mark.parametrize("seed", range(24))

@@ -20,6 +20,9 @@ def _free_port():
     return p
 
 
+LAM_C = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.7, lambda_r=1e-3, lambda_count=0.5, lambda_f_reg=2.0)
+
+
 def _worker(rank, world, port, sim_path, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -34,13 +37,21 @@ def _worker(rank, world, port, sim_path, outdir):
         M0 = orc.reference_init_M(C, V, 5)
         lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
         sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam)
+        assert sh.transport == "callbacks"
         n = 4
         hist = sh.eng.new_history(n)
-        sh.run(n, 0.1, hist)
-        hist = sh.finalize_history(hist)
+        sh.run(n, 0.1, hist)               # ONE call of the C library: kernels + the three exchanges per step (gloo through callbacks)
         P = sh.result_full()
-        if rank == 0:
-            np.savez(os.path.join(outdir, "sharded.npz"), P=P.numpy(), hist=hist.numpy())
+        # MapperConstrained on shards: the filter F is replicated, its gradient comes from the all-reduced row sums
+        M0c, F0c = orc.reference_init_MF_constrained(C, V, 5)
+        shc = make_sharded(data["S"], data["G"], M0c, d=data["d"], F0=F0c, mode="constrained", device="cpu", precision="fp32",
+                           lambdas=LAM_C, target_count=40.0)
+        hc = shc.eng.new_history(n)
+        shc.run(n, 0.1, hc)
+        Pc, Fc = shc.result_full(with_filter=True)
+        Gc = shc.project_full()
+        np.savez(os.path.join(outdir, f"sharded_{rank}.npz"), P=P.numpy(), hist=hist.numpy(), Pc=Pc.numpy(), Fc=Fc.numpy(),
+                 hc=hc.numpy(), Gc=Gc.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -51,7 +62,10 @@ def test_two_shards_match_single_and_oracle(tmp_path):
         pytest.skip("host clang not available to build the emulator")
     port = _free_port()
     mp.spawn(_worker, args=(2, port, sim_path, str(tmp_path)), nprocs=2, join=True)
-    z = np.load(tmp_path / "sharded.npz")
+    z = np.load(tmp_path / "sharded_0.npz")
+    z1 = np.load(tmp_path / "sharded_1.npz")
+    for k in z.files:                                    # every rank holds the same global history, mapping, filter, projection
+        np.testing.assert_array_equal(z[k], z1[k], err_msg=k)
 
     from tangram_amd import _capi
     from tangram_amd.engine import HipMapperEngine
@@ -77,3 +91,71 @@ def test_two_shards_match_single_and_oracle(tmp_path):
     for j, k in zip(cols, ["total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg"]):
         np.testing.assert_allclose(z["hist"][:, j], np.array(ho[k]), atol=1e-5, rtol=1e-5, err_msg=k)
     assert np.abs(z["P"] - Po).max() < 1e-5
+    # constrained
+    M0c, F0c = orc.reference_init_MF_constrained(C, V, 5)
+    oc = orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0c, F0=F0c, target_count=40.0, dtype=np.float64, **LAM_C)
+    Pco, Fco, hco = oc.train(n, 0.1)
+    colsc = {_capi.H_TOTAL: "total_loss", _capi.H_MAIN: "main_loss", _capi.H_VG: "vg_reg", _capi.H_KL: "kl_reg",
+             _capi.H_ENTROPY: "entropy_reg", _capi.H_COUNT: "count_reg", _capi.H_FREG: "lambda_f_reg"}
+    for j, k in colsc.items():
+        np.testing.assert_allclose(z["hc"][:, j], np.array(hco[k], dtype=np.float64), atol=2e-5, rtol=1e-5, err_msg="constrained " + k)
+    assert np.abs(z["Pc"] - Pco).max() < 1e-5 and np.abs(z["Fc"] - Fco).max() < 1e-5
+    f = Fco[:, None]
+    ref = (Pco * f).T @ data["S"].astype(np.float64)
+    assert np.linalg.norm(z["Gc"] - ref) / np.linalg.norm(ref) < 1e-5
+
+
+def _seam_worker(rank, world, port, sim_path, outdir):
+    """The drop-in surface under a process group: the SAME call on every rank (what a user runs under torchrun)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tangram_amd import _capi
+        _capi._install_library_for_tests(sim_path)
+        import tangram_amd as tg
+        from tests.test_map_cells_to_space import _adatas
+        out = {}
+        for mode, kw in (("cells", {}), ("clusters", dict(cluster_label="subclass_label")), ("constrained", dict(target_count=9))):
+            ad_sc, ad_sp = _adatas(C=70, K=14, V=150)
+            ad_map = tg.map_cells_to_space(ad_sc, ad_sp, mode=mode, device="cpu", num_epochs=5, random_state=42, verbose=False,
+                                           gemm_precision="fp32", lambda_g2=0.4, **kw)
+            out[mode + "_X"] = ad_map.X
+            out[mode + "_score"] = ad_map.uns["train_genes_df"]["train_score"].sort_index().to_numpy()
+            out[mode + "_loss"] = np.array([float(x) for x in ad_map.uns["training_history"]["total_loss"]])
+            if mode == "constrained":
+                out["constrained_F"] = np.asarray(ad_map.obs["F_out"])
+        np.savez(os.path.join(outdir, f"seam_{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_map_cells_to_space_shards_over_the_process_group(tmp_path):
+    """`map_cells_to_space` / `Mapper` / `MapperConstrained` under an initialised process group of 2 ranks shard the spots
+    (reference seam mapping_utils.py:355-389 carries only `device`): every rank gets the full mapping, equal to the
+    single-process run of the same call."""
+    sim_path = build_sim()
+    if sim_path is None:
+        pytest.skip("host clang not available to build the emulator")
+    mp.spawn(_seam_worker, args=(2, _free_port(), sim_path, str(tmp_path)), nprocs=2, join=True)
+    z0, z1 = np.load(tmp_path / "seam_0.npz"), np.load(tmp_path / "seam_1.npz")
+    from tangram_amd import _capi
+    import tangram_amd as tg
+    from tests.test_map_cells_to_space import _adatas
+    _capi._install_library_for_tests(sim_path)
+    try:
+        for mode, kw in (("cells", {}), ("clusters", dict(cluster_label="subclass_label")), ("constrained", dict(target_count=9))):
+            ad_sc, ad_sp = _adatas(C=70, K=14, V=150)
+            ad_map = tg.map_cells_to_space(ad_sc, ad_sp, mode=mode, device="cpu", num_epochs=5, random_state=42, verbose=False,
+                                           gemm_precision="fp32", lambda_g2=0.4, **kw)
+            for z in (z0, z1):
+                np.testing.assert_allclose(z[mode + "_X"], ad_map.X, atol=2e-6, err_msg=mode)
+                np.testing.assert_allclose(z[mode + "_loss"], [float(x) for x in ad_map.uns["training_history"]["total_loss"]],
+                                           atol=1e-5, rtol=1e-6, err_msg=mode)
+                np.testing.assert_allclose(z[mode + "_score"], ad_map.uns["train_genes_df"]["train_score"].sort_index().to_numpy(),
+                                           atol=1e-5, err_msg=mode)
+            np.testing.assert_array_equal(z0[mode + "_X"], z1[mode + "_X"])
+            if mode == "constrained":
+                np.testing.assert_allclose(z0["constrained_F"], np.asarray(ad_map.obs["F_out"]), atol=2e-6)
+    finally:
+        _capi._install_library_for_tests(None)
