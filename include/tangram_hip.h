@@ -178,6 +178,23 @@ int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t ld_s, int3
 int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_dev, const float* data_dev, int64_t n_rows,
                             int32_t col0, int32_t n_cols, float* out_dev, int64_t ld_out, void* hip_stream);
 
+/* ---- host pre-processing on the device (no handle; enqueued on `hip_stream`) -------------------------------------------------
+ * Replaces `adata[:, training_genes].X.toarray()` on the host (mapping_utils.py:259-275): the selected gene columns of a cells x genes
+ * (or spots x genes) CSR matrix written straight into the dense S / G the mapper consumes.  colmap_dev[j] = destination column of
+ * source column j, or -1; values are copied (bit-identical to the host gather).                                                  */
+int tg_csr_gather_columns(const int64_t* indptr_dev, const int32_t* indices_dev, const float* data_dev, int64_t n_rows,
+                          const int32_t* colmap_dev, int32_t n_out_cols, float* out_dev, int64_t ld_out, void* hip_stream);
+/* Replaces `np.array(adata_sp.X.sum(axis=1)).squeeze()` and, with normalize != 0, `/ np.sum(rna_count_per_spot)` (pp_adatas,
+ * mapping_utils.py:88-89): row sums of a dense (X_dev, ld, n_cols) or CSR (X_dev = NULL; indptr_dev, data_dev) matrix, accumulated
+ * in double, rounded once; normalize: divided by their total (also double) -> the rna_count_based density prior.               */
+int tg_row_sums(const float* X_dev, int64_t ld, int32_t n_cols, const int64_t* indptr_dev, const float* data_dev, int64_t n_rows,
+                float* out_dev, int32_t normalize, void* hip_stream);
+/* Replaces the per-cluster `adata[mask].X.sum(axis=0)` / `.mean(axis=0)` loop of adata_to_cluster_expression (mapping_utils.py:126-132):
+ * out_dev[c][k] = sum (mean != 0: mean) of X_dev[r][k] over the member rows r of cluster c (member_rows_dev[member_indptr_dev[c] ..
+ * member_indptr_dev[c+1])), accumulated in double in member order.                                                              */
+int tg_cluster_aggregate(const float* X_dev, int64_t ld, int32_t n_cols, const int32_t* member_indptr_dev, const int32_t* member_rows_dev,
+                         int32_t n_clusters, int32_t mean, float* out_dev, int64_t ld_out, void* hip_stream);
+
 /* Replaces Mapper._val_loss_fn (mapping_optimizer.py:311-356), evaluated with the CURRENT logits:
  * out4_dev = { gene score + voxel score, gene score, sparsity-weighted gene score, normalised map entropy }.   */
 int tg_mapper_validate(tg_mapper* m, float* out4_dev);

@@ -72,6 +72,11 @@ def _declare(lib):
     lib.tg_mapper_project_genes.argtypes = [vp, vp, ct.c_int64, i32, vp, ct.c_int64, i32]
     lib.tg_csr_columns_to_dense.argtypes = [vp, vp, vp, ct.c_int64, i32, i32, vp, ct.c_int64, vp]
     lib.tg_csr_columns_to_dense.restype = i32
+    lib.tg_csr_gather_columns.argtypes = [vp, vp, vp, ct.c_int64, vp, i32, vp, ct.c_int64, vp]
+    lib.tg_row_sums.argtypes = [vp, ct.c_int64, i32, vp, vp, ct.c_int64, vp, i32, vp]
+    lib.tg_cluster_aggregate.argtypes = [vp, ct.c_int64, i32, vp, vp, i32, i32, vp, ct.c_int64, vp]
+    for name in ("tg_csr_gather_columns", "tg_row_sums", "tg_cluster_aggregate"):
+        getattr(lib, name).restype = i32
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
     lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
@@ -89,7 +94,8 @@ def _declare(lib):
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
            "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_destroy",
            "tg_mapper_attach_comm", "tg_mapper_result",
-           "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
+           "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
+           "tg_cluster_aggregate", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
            "tg_mapper_profile_read", "tg_mapper_validate"]
 
 

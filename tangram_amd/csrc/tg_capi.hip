@@ -1185,6 +1185,39 @@ extern "C" int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t*
     return TG_OK;
 }
 
+extern "C" int tg_csr_gather_columns(const int64_t* indptr_dev, const int32_t* indices_dev, const float* data_dev, int64_t n_rows,
+                                     const int32_t* colmap_dev, int32_t n_out_cols, float* out_dev, int64_t ld_out, void* hip_stream) {
+    if (!indptr_dev || !indices_dev || !data_dev || !colmap_dev || !out_dev) return tg_fail(TG_ERR_INVALID, "null argument");
+    if (n_rows < 1 || n_out_cols < 1 || ld_out < n_out_cols) return tg_fail(TG_ERR_INVALID, "bad gather: rows %lld, columns %d, pitch %lld",
+                                                                            (long long)n_rows, n_out_cols, (long long)ld_out);
+    TG_LAUNCH(tg_csr_gather_cols, n_rows, 1, 256, 0, (tg_stream_t)hip_stream, (const long long*)indptr_dev, (const int*)indices_dev, data_dev,
+              (const int*)colmap_dev, n_out_cols, out_dev, (long long)ld_out);
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
+
+extern "C" int tg_row_sums(const float* X_dev, int64_t ld, int32_t n_cols, const int64_t* indptr_dev, const float* data_dev, int64_t n_rows,
+                           float* out_dev, int32_t normalize, void* hip_stream) {
+    if (!out_dev || (!X_dev && !(indptr_dev && data_dev))) return tg_fail(TG_ERR_INVALID, "null argument");
+    if (n_rows < 1 || (X_dev && (n_cols < 1 || ld < n_cols))) return tg_fail(TG_ERR_INVALID, "bad matrix shape");
+    TG_LAUNCH(tg_row_sums, (n_rows + 3) / 4, 1, 256, 4 * 64 * 8, (tg_stream_t)hip_stream, X_dev, (long long)ld, n_cols,
+              X_dev ? (const long long*)nullptr : (const long long*)indptr_dev, data_dev, (long long)n_rows, out_dev);
+    if (normalize) TG_LAUNCH(tg_normalize_total, 1, 1, 1024, 1024 * 8, (tg_stream_t)hip_stream, out_dev, (long long)n_rows);
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
+
+extern "C" int tg_cluster_aggregate(const float* X_dev, int64_t ld, int32_t n_cols, const int32_t* member_indptr_dev,
+                                    const int32_t* member_rows_dev, int32_t n_clusters, int32_t mean, float* out_dev, int64_t ld_out,
+                                    void* hip_stream) {
+    if (!X_dev || !member_indptr_dev || !member_rows_dev || !out_dev) return tg_fail(TG_ERR_INVALID, "null argument");
+    if (n_clusters < 1 || n_cols < 1 || ld < n_cols || ld_out < n_cols) return tg_fail(TG_ERR_INVALID, "bad aggregation shape");
+    TG_LAUNCH(tg_cluster_sums, n_clusters, (n_cols + 255) / 256, 256, 0, (tg_stream_t)hip_stream, X_dev, (long long)ld, n_cols,
+              (const int*)member_indptr_dev, (const int*)member_rows_dev, mean, out_dev, (long long)ld_out);
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
+
 extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (!out4_dev) return tg_fail(TG_ERR_INVALID, "out is NULL");

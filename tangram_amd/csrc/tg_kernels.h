@@ -359,6 +359,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
     // SLOWER (bf16x3 2.45 ms): VALU in the MFMA stream costs far more than its issue slots (profiles/r02/README.md).
     constexpr int STAG = (TG_FWD_STAGGER >= 0) ? TG_FWD_STAGGER : ((PR::kId == 1) ? 2 : 0);
     const bool early = (STAG == 1) ? (wave < GE::NT / 128) : ((STAG == 2) ? (wave >= GE::NT / 128) : false);
+    // (every wave early -- all M loads a full step ahead, VALU block first: bf16x3 1.63 ms, bf16 0.77: the M loads do not cost latency)
     if (s_begin < s_end) {
         tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)s_begin, lds + GE::A_CHUNKS, t, wave);
         load_stage(s_begin);
@@ -1840,6 +1841,76 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_csr_cols_to_dense(const long long* indpt
         const int c = indices[i] - col0;
         if (c >= 0 && c < ncols) o[c] = data[i];           // (canonical CSR: one entry per (row, column))
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Host pre-processing on the device: what map_cells_to_space / pp_adatas do with NumPy before the first iteration
+// ----------------------------------------------------------------------------------------------
+// out[row][colmap[j]] = X[row][j] for the selected columns (colmap[j] >= 0) of a CSR matrix: the training-gene columns of
+// adata_sc.X / adata_sp.X straight into the dense S / G of the mapper (mapping_utils.py:259-275: `adata[:, genes].X.toarray()`
+// on the host).  One workgroup per row; values are copied, so the result is bit-identical to the host gather.
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_csr_gather_cols(const long long* indptr, const int* indices, const float* data, const int* colmap,
+                                                        int ncols_out, float* out, long long ld_out) {
+    const long long row = blockIdx.x;
+    float* o = out + row * ld_out;
+    for (int k = threadIdx.x; k < ncols_out; k += 256) o[k] = 0.f;
+    __syncthreads();
+    const long long beg = indptr[row], end = indptr[row + 1];
+    for (long long i = beg + threadIdx.x; i < end; i += 256) {
+        const int c = colmap[indices[i]];
+        if (c >= 0) o[c] = data[i];                        // (canonical CSR: one entry per (row, column))
+    }
+}
+
+// out[row] = sum of the row, accumulated in DOUBLE (one wave per row, 64 partial sums combined in lane order: fixed order) and
+// rounded once: `adata_sp.X.sum(axis=1)` of pp_adatas (mapping_utils.py:88).  Dense (X, ld, ncols) or CSR (indptr, data).
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_row_sums(const float* X, long long ld, int ncols, const long long* indptr, const float* data,
+                                                 long long nrows, float* out) {
+    TG_LDS_DECL;
+    double* red = (double*)tg_lds;                         // [4 waves][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    double s = 0.0;
+    if (row < nrows) {
+        if (indptr) { for (long long i = indptr[row] + lane; i < indptr[row + 1]; i += 64) s += (double)data[i]; }
+        else { for (int k = lane; k < ncols; k += 64) s += (double)X[row * ld + k]; }
+    }
+    red[wave * 64 + lane] = s;
+    __syncthreads();
+    if (lane == 0 && row < nrows) {
+        double t = 0.0;
+        for (int i = 0; i < 64; ++i) t += red[wave * 64 + i];
+        out[row] = (float)t;
+    }
+}
+
+// x[i] /= sum(x) with the total in double (one block, fixed order): rna_count_based_density (mapping_utils.py:89)
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_normalize_total(float* x, long long n) {
+    TG_LDS_DECL;
+    double* red = (double*)tg_lds;                         // [1024]
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    const double tot = red[0];
+    for (long long i = threadIdx.x; i < n; i += 1024) x[i] = (float)((double)x[i] / tot);
+}
+
+// out[cluster][k] = sum (or mean) over the member rows of X[.][k], accumulated in double in member order: adata_to_cluster_expression
+// (mapping_utils.py:126-132).  members = CSR-like lists of row indices per cluster.  grid = (clusters, column blocks of 256).
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_cluster_sums(const float* X, long long ld, int ncols, const int* member_indptr, const int* member_rows,
+                                                     int mean, float* out, long long ld_out) {
+    const int cl = blockIdx.x, k = blockIdx.y * 256 + threadIdx.x;
+    if (k >= ncols) return;
+    const int b = member_indptr[cl], e = member_indptr[cl + 1];
+    double s = 0.0;
+    for (int i = b; i < e; ++i) s += (double)X[(long long)member_rows[i] * ld + k];
+    if (mean) s /= (double)(e - b);                         // (an empty cluster yields NaN like NumPy's mean of nothing)
+    out[(long long)cl * ld_out + k] = (float)s;
 }
 
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_fill(float* p, size_t n, float val) {

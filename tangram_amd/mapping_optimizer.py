@@ -44,10 +44,12 @@ _PRINT_NAMES = [  # reference :286-298, with the history column each comes from
 
 
 def _to_numpy_f32(x):
+    """float32 array for the engine: a torch tensor stays a tensor (a DEVICE tensor is consumed where it is: no host round
+    trip for matrices that were built on the GPU, tangram_amd.preprocess), everything else becomes a contiguous ndarray."""
     if x is None:
         return None
     if isinstance(x, torch.Tensor):
-        return x.detach().cpu().numpy().astype(np.float32)
+        return x.detach().to(torch.float32)
     if hasattr(x, "to_numpy"):            # pandas Series (density priors come from adata.obs)
         x = x.to_numpy()
     return np.ascontiguousarray(np.asarray(x, dtype=np.float32))

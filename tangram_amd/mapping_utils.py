@@ -39,6 +39,26 @@ def _dense(X):
     raise NotImplementedError("AnnData X has unrecognized type: {}".format(type(X)))   # reference :264-266
 
 
+def _training_matrix(adata, view, training_genes, device):
+    """The [n_obs, K] float32 matrix of the training genes (reference :259-275).  A sparse `adata.X` is NOT densified on the host:
+    its CSR arrays are uploaded once and the training-gene columns are gathered on the device (tangram_amd.preprocess) -- a
+    float32 DEVICE tensor comes back, which `Mapper` consumes as it is.  Dense matrices take the host path like the reference."""
+    X = adata.X
+    if hasattr(X, "tocsr") and not isinstance(X, np.matrix):
+        from . import preprocess as pre
+        cols = pd.Index(adata.var.index).get_indexer(list(training_genes))
+        if (cols < 0).any():
+            raise ValueError("Given training genes list should be subset of two AnnDatas.")
+        return pre.gather_training_genes(X, cols, device)
+    return np.array(_dense(view.X), dtype="float32")
+
+
+def _all_genes_expressed(A):
+    if isinstance(A, torch.Tensor):
+        return bool((A != 0).any(dim=0).all().item())
+    return bool(A.any(axis=0).all())
+
+
 def annotate_gene_sparsity(adata):
     """reference tangram/utils.py:46-61"""
     X = adata.X
@@ -47,9 +67,39 @@ def annotate_gene_sparsity(adata):
     adata.var["sparsity"] = 1 - gene_sparsity
 
 
-def adata_to_cluster_expression(adata, cluster_label, scale=True, add_density=True):
+def density_priors(adata_sp, device="cuda:0"):
+    """The two density priors of `pp_adatas` (reference tangram/mapping_utils.py:81-89) written to `adata_sp.obs`:
+    `uniform_density` = 1 / n_spots and `rna_count_based_density` = fraction of the RNA counts per spot -- the row sums of
+    `adata_sp.X` (sparse stays sparse) taken on the device in double (tangram_amd.preprocess.rna_count_density)."""
+    from . import preprocess as pre
+    n = adata_sp.X.shape[0]
+    adata_sp.obs["uniform_density"] = np.ones(n) / n
+    adata_sp.obs["rna_count_based_density"] = pre.rna_count_density(adata_sp.X, device).cpu().numpy()
+
+
+def _cluster_sums_on_device(X, labels, unique_labels, scale, device, block=4096):
+    """[n_clusters, n_genes] float64 like the reference's X_new, gene block by gene block: the block of columns is gathered on
+    the device (CSR uploaded once; a dense X is uploaded block-wise) and reduced per cluster by tg_cluster_aggregate."""
+    from . import preprocess as pre
+    n_genes = X.shape[1]
+    out = np.empty((len(unique_labels), n_genes))
+    dev = pre._check_device(device)
+    csr = pre.DeviceCSR(X, dev) if hasattr(X, "tocsr") else None
+    for k0 in range(0, n_genes, block):
+        k1 = min(n_genes, k0 + block)
+        if csr is not None:
+            blk = pre.gather_training_genes(csr, np.arange(k0, k1), dev)
+        else:
+            blk = torch.as_tensor(np.ascontiguousarray(np.asarray(X)[:, k0:k1], dtype=np.float32), device=dev)
+        out[:, k0:k1] = pre.cluster_expression(blk, labels, unique_labels, scale=scale).cpu().numpy()
+    return out
+
+
+def adata_to_cluster_expression(adata, cluster_label, scale=True, add_density=True, *, device=None):
     """Cluster-level expression (reference tangram/mapping_utils.py:103-139): one observation per cluster,
-    sum (scale=True) or mean of its cells; `obs['cluster_density']` = fraction of cells per cluster."""
+    sum (scale=True) or mean of its cells; `obs['cluster_density']` = fraction of cells per cluster.
+    Extra keyword `device`: run the per-cluster reductions on that HIP device (double accumulation, the sparse matrix is
+    uploaded as CSR and never densified on the host) instead of the NumPy loop."""
     try:
         value_counts = adata.obs[cluster_label].value_counts(normalize=True)
     except KeyError:
@@ -58,8 +108,13 @@ def adata_to_cluster_expression(adata, cluster_label, scale=True, add_density=Tr
     new_obs = pd.DataFrame({cluster_label: unique_labels})
     X = adata.X
     labels = adata.obs[cluster_label].to_numpy()
-    X_new = np.empty((len(unique_labels), adata.shape[1]))
+    if device is not None:
+        X_new = _cluster_sums_on_device(X, labels, list(unique_labels), scale, device)
+    else:
+        X_new = np.empty((len(unique_labels), adata.shape[1]))
     for index, l in enumerate(unique_labels):
+        if device is not None:
+            break
         rows = np.where(labels == l)[0]
         sub = X[rows]
         X_new[index] = np.asarray(sub.mean(axis=0) if not scale else sub.sum(axis=0)).reshape(-1)
@@ -122,8 +177,8 @@ def map_cells_to_space(
     if mode == "constrained" and not all([target_count, lambda_f_reg, lambda_count]):
         raise ValueError("target_count, lambda_f_reg and lambda_count must be specified if mode is 'constrained'.")
 
-    if mode == "clusters":                                                     # :231-234
-        adata_sc = adata_to_cluster_expression(adata_sc, cluster_label, scale, add_density=True)
+    if mode == "clusters":                                                     # :231-234 (reductions on the device)
+        adata_sc = adata_to_cluster_expression(adata_sc, cluster_label, scale, add_density=True, device=device)
 
     # ---- tangram parameters in uns, :236-254
     if not set(["training_genes", "overlap_genes"]).issubset(set(adata_sc.uns.keys())):
@@ -142,9 +197,9 @@ def map_cells_to_space(
     logging.info("Allocate tensors for mapping.")
     sc_view = adata_sc[:, training_genes]
     sp_view = adata_sp[:, training_genes]
-    S = np.array(_dense(sc_view.X), dtype="float32")                          # :259-266
-    G = np.array(_dense(sp_view.X), dtype="float32")                          # :268-275
-    if not S.any(axis=0).all() or not G.any(axis=0).all():                    # :277
+    S = _training_matrix(adata_sc, sc_view, training_genes, device)           # :259-266
+    G = _training_matrix(adata_sp, sp_view, training_genes, device)           # :268-275
+    if not _all_genes_expressed(S) or not _all_genes_expressed(G):            # :277
         raise ValueError("Genes with all zero values detected. Run `pp_adatas()`.")
 
     # ---- density prior, :280-307
@@ -218,12 +273,13 @@ def map_cells_to_space(
 
     # ---- per-gene training score, :401-410 (projection evaluated on the GPU; constrained: unfiltered like :402)
     if mode == "constrained":
-        G_predicted = mapper.project_genes_device(S, unfiltered=True).cpu().numpy()
+        G_predicted = mapper.project_genes_device(S, unfiltered=True)
     else:
-        G_predicted = mapper.project_genes_device().cpu().numpy()
-    num = (G * G_predicted).sum(axis=0)
-    den = np.linalg.norm(G, axis=0) * np.linalg.norm(G_predicted, axis=0)
-    cos_sims = num / den
+        G_predicted = mapper.project_genes_device()
+    G_dev = torch.as_tensor(G).to(device=G_predicted.device, dtype=torch.float32)
+    num = (G_dev * G_predicted).sum(dim=0)
+    den = torch.linalg.norm(G_dev, dim=0) * torch.linalg.norm(G_predicted, dim=0)
+    cos_sims = (num / den).cpu().numpy()
     df_cs = pd.DataFrame(cos_sims, list(training_genes), columns=["train_score"])
     df_cs = df_cs.sort_values(by="train_score", ascending=False)
     adata_map.uns["train_genes_df"] = df_cs

@@ -488,3 +488,26 @@ def test_project_genes_from_sparse_single_cell_matrix():
     b = e.project_genes(dense).cpu().numpy()
     np.testing.assert_array_equal(a, b)
     assert a.shape == (V, K_all) and np.isfinite(a).all() and a.max() > 0
+
+
+def test_device_preprocessing():
+    """SURVEY 8 f-4 on the GPU: CSR gather of gene columns bit-exact, density prior and cluster sums within 1 ulp of the exactly
+    rounded result (same checks as the emulated CPU test)."""
+    from tests.test_preprocess import check_preprocessing
+    check_preprocessing(DEV)
+
+
+def test_map_cells_to_space_sparse_input_on_gpu():
+    """map_cells_to_space fed with scipy-sparse AnnData matrices (training genes gathered on the device) equals the dense-input run."""
+    import scipy.sparse as sp
+    import tangram_amd as tg
+    from tangram_amd.anndata_lite import AnnDataLite
+    from tests.test_map_cells_to_space import _adatas
+    for mode, kw in (("cells", {}), ("clusters", dict(cluster_label="subclass_label"))):
+        ad_sc, ad_sp = _adatas(C=300, K=40, V=130, extra_genes=25)
+        dense = tg.map_cells_to_space(ad_sc, ad_sp, mode=mode, device=DEV, num_epochs=8, random_state=42, verbose=False, **kw)
+        ad_sc2, ad_sp2 = _adatas(C=300, K=40, V=130, extra_genes=25)
+        ad_sc2 = AnnDataLite(sp.csr_matrix(ad_sc2.X), obs=ad_sc2.obs, var=ad_sc2.var, uns=ad_sc2.uns)
+        ad_sp2 = AnnDataLite(sp.csr_matrix(ad_sp2.X), obs=ad_sp2.obs, var=ad_sp2.var, uns=ad_sp2.uns)
+        sparse = tg.map_cells_to_space(ad_sc2, ad_sp2, mode=mode, device=DEV, num_epochs=8, random_state=42, verbose=False, **kw)
+        np.testing.assert_allclose(sparse.X, dense.X, atol=2e-6, err_msg=mode)
