@@ -178,6 +178,20 @@ int tg_mapper_project_genes(tg_mapper* m, const float* S_dev, int64_t ld_s, int3
 int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_dev, const float* data_dev, int64_t n_rows,
                             int32_t col0, int32_t n_cols, float* out_dev, int64_t ld_out, void* hip_stream);
 
+/* ---- batched independent mappings ------------------------------------------------------------------------------
+ * The reference trains independent mappings one after the other: one per held-out gene in `cross_val` (utils.py:576-600; 249 in
+ * the tutorial), three seeds per trial in the tuner (mapping_parameter_tuning.py:109-131).  A tg_batch advances B Mapper handles
+ * of ONE shape / configuration together: every kernel of the iteration is launched once with blockIdx.z = mapping (its arguments
+ * come from arrays in `scratch_dev`, tg_batch_query_bytes(B) bytes of device memory).  The handles stay usable on their own
+ * (result, project, state); they must share the stream they were created on and stay at the same step.  Results are the bits of
+ * stepping each handle alone.  Mapper mode without spatial terms, rows <= 16 384 spots.
+ * history_dev: host array of B device pointers (one history buffer per mapping) or NULL.                                        */
+typedef struct tg_batch tg_batch;
+size_t tg_batch_query_bytes(int n_mappers);
+int tg_batch_create(tg_mapper* const* mappers, int n_mappers, void* scratch_dev, tg_batch** out);
+int tg_batch_step(tg_batch* b, int n_steps, float lr, float* const* history_dev, int first_row);
+void tg_batch_destroy(tg_batch* b);
+
 /* ---- host pre-processing on the device (no handle; enqueued on `hip_stream`) -------------------------------------------------
  * Replaces `adata[:, training_genes].X.toarray()` on the host (mapping_utils.py:259-275): the selected gene columns of a cells x genes
  * (or spots x genes) CSR matrix written straight into the dense S / G the mapper consumes.  colmap_dev[j] = destination column of

@@ -1,5 +1,6 @@
-"""N independent clusters-mode mappings (18 clusters x 250 genes x 9852 spots, 1000 epochs: the tutorial's
-cross-validation unit) one after the other vs side by side on one GPU (tangram_amd.batched.train_many)."""
+"""B independent clusters-mode mappings (18 clusters x 250 genes x 9852 spots: the tutorial's cross-validation
+unit, utils.py:576-600) -- one fold alone vs B folds in ONE launch per kernel (tg_batch, blockIdx.z = fold) vs one HIP stream +
+host thread per fold.  Timed on engine steps (construction / result copies excluded), then end to end through train_many."""
 import json
 import os
 import sys
@@ -10,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tangram_amd.mapping_optimizer as mo  # noqa: E402
-from tangram_amd.batched import train_many  # noqa: E402
+from tangram_amd.batched import train_many, MapperBatch  # noqa: E402
 from tangram_amd.synthetic import make_workload  # noqa: E402
 
 
@@ -25,21 +26,46 @@ def main():
         keep = [g for g in range(K + N) if g != i][:K]
         return lambda: mo.Mapper(S=S_all[:, keep], G=G_all[:, keep], d=d, d_source=ds, lambda_d=1, device=dev, random_state=i + 1)     # (0 would mean "unseeded", like the reference)
 
+    out = {"epochs": EPOCHS, "shape": [C, K, V]}
+    # --- pure stepping rate: one fold alone, then B folds per launch
+    m1 = builder(0)()
+    m1._engine.step(100, 0.1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m1._engine.step(EPOCHS, 0.1)
+    torch.cuda.synchronize()
+    t1 = (time.perf_counter() - t0) / EPOCHS
+    out["one_fold_us_per_iter"] = 1e6 * t1
+    for B in (2, 4, 8, 16):
+        ms = [builder(i)() for i in range(B)]
+        batch = MapperBatch(ms)
+        batch.step(100, 0.1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        batch.step(EPOCHS, 0.1)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / EPOCHS
+        out[f"batch_{B}"] = {"us_per_batch_iter": 1e6 * tb, "fold_iters_per_s": B / tb, "speedup_vs_one_fold": B * t1 / tb}
+        batch.close()
+        for m in ms:
+            m.release()
+    # --- end to end through train_many (construction, training, result copies), 16 folds
     builders = [builder(i) for i in range(N)]
-    builders[0]().train(num_epochs=50, learning_rate=0.1, print_each=None)      # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     seq = [b().train(num_epochs=EPOCHS, learning_rate=0.1, print_each=None) for b in builders]
     torch.cuda.synchronize()
     t_seq = time.perf_counter() - t0
-    out = {"mappings": N, "epochs": EPOCHS, "shape": [C, K, V], "sequential_s": t_seq, "sequential_us_per_iter": 1e6 * t_seq / (N * EPOCHS)}
-    for conc in (2, 4, 8, 16):
+    out["train_sequential_s"] = t_seq
+    for label, kw in (("train_many_batched", dict(batched="auto")), ("train_many_streams_4", dict(batched=False, max_concurrent=4))):
         t0 = time.perf_counter()
-        res, _ = train_many(builders, EPOCHS, 0.1, max_concurrent=conc, device=dev)
+        res, ms = train_many(builders, EPOCHS, 0.1, device=dev, **kw)
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
-        same = all(np.array_equal(a[0], b[0]) for a, b in zip(seq, res))
-        out[f"concurrent_{conc}"] = {"seconds": t, "us_per_iter": 1e6 * t / (N * EPOCHS), "speedup": t_seq / t, "bit_identical": bool(same)}
+        same = all(np.array_equal(a[0], b[0]) and list(a[1]["main_loss"]) == list(b[1]["main_loss"]) for a, b in zip(seq, res))
+        out[label] = {"seconds": t, "speedup": t_seq / t, "bit_identical_to_sequential": bool(same)}
+        for m in ms:
+            m.release()
     print(json.dumps(out))
 
 

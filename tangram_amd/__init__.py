@@ -5,6 +5,6 @@ from .mapping_optimizer import Mapper, MapperConstrained          # noqa: F401
 from .mapping_utils import map_cells_to_space, adata_to_cluster_expression, density_priors  # noqa: F401
 from . import preprocess                                          # noqa: F401
 from .utils import project_genes                                  # noqa: F401
-from .batched import train_many                                   # noqa: F401
+from .batched import train_many, MapperBatch                                   # noqa: F401
 
 __version__ = "0.1.0"

@@ -72,6 +72,14 @@ def _declare(lib):
     lib.tg_mapper_project_genes.argtypes = [vp, vp, ct.c_int64, i32, vp, ct.c_int64, i32]
     lib.tg_csr_columns_to_dense.argtypes = [vp, vp, vp, ct.c_int64, i32, i32, vp, ct.c_int64, vp]
     lib.tg_csr_columns_to_dense.restype = i32
+    lib.tg_batch_query_bytes.argtypes = [i32]
+    lib.tg_batch_query_bytes.restype = ct.c_size_t
+    lib.tg_batch_create.argtypes = [ct.POINTER(vp), i32, vp, ct.POINTER(vp)]
+    lib.tg_batch_create.restype = i32
+    lib.tg_batch_step.argtypes = [vp, i32, f32, ct.POINTER(vp), i32]
+    lib.tg_batch_step.restype = i32
+    lib.tg_batch_destroy.argtypes = [vp]
+    lib.tg_batch_destroy.restype = None
     lib.tg_csr_gather_columns.argtypes = [vp, vp, vp, ct.c_int64, vp, i32, vp, ct.c_int64, vp]
     lib.tg_row_sums.argtypes = [vp, ct.c_int64, i32, vp, vp, ct.c_int64, vp, i32, vp]
     lib.tg_cluster_aggregate.argtypes = [vp, ct.c_int64, i32, vp, vp, i32, i32, vp, ct.c_int64, vp]
@@ -95,7 +103,7 @@ EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_creat
            "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_destroy",
            "tg_mapper_attach_comm", "tg_mapper_result",
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
-           "tg_cluster_aggregate", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
+           "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
            "tg_mapper_profile_read", "tg_mapper_validate"]
 
 

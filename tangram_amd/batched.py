@@ -3,31 +3,118 @@ Independent mappings side by side on one GPU.
 
 The reference runs independent mappings strictly one after the other: `cross_val` trains one mapping per held-out gene
 (utils.py:576-600; 249 in the tutorial), the tuning driver three seeds per trial (mapping_parameter_tuning.py:109-131).
-Clusters-mode problems are tiny (18 x 250 x 9852) and latency-bound on a 256-CU GPU: one iteration is ~7 dependent
-kernels of ~10 us that each occupy a fraction of the chip.  `train_many` gives every mapping its own HIP stream and its
-own host thread (the C ABI releases the GIL for the whole `tg_mapper_step` loop, and different handles may be driven from
-different threads), so the kernels of different mappings fill the idle CUs.  Results are bit-identical to training the
-same mappings one by one: nothing is shared between handles.
+Clusters-mode problems are tiny (18 x 250 x 9852) and launch-bound on a 256-CU GPU: one iteration is ~6 dependent kernels of
+~10 us that each occupy a fraction of the chip.
+
+`MapperBatch` / `train_many` advance B mappings of one shape in ONE launch per kernel: the C library's `tg_batch` puts the
+per-mapping kernel arguments into device arrays and adds a batch index to the grid of every kernel of the iteration
+(blockIdx.z = mapping).  Results are the bits of training the same mappings one by one: nothing is shared between them.
+Mappings that cannot be batched (different shapes, MapperConstrained, spatial terms, `val_each`) fall back to one HIP stream
+and host thread per mapping (the C ABI releases the GIL; different handles may be driven from different threads).
 """
 from __future__ import annotations
 
+import ctypes as ct
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
+from . import _capi
 
-def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device="cuda:0", **train_kwargs):
-    """Train independent mappings concurrently.
+
+class MapperBatch:
+    """B `Mapper`s of one shape / configuration stepped together (tg_batch)."""
+
+    def __init__(self, mappers):
+        self.mappers = list(mappers)
+        if not self.mappers:
+            raise ValueError("empty batch")
+        engines = [m._engine for m in self.mappers]
+        self.engines = engines
+        e0 = engines[0]
+        self._lib = e0._lib
+        n = len(engines)
+        self._scratch = torch.empty(int(self._lib.tg_batch_query_bytes(n)), dtype=torch.uint8, device=e0.device)
+        arr = (ct.c_void_p * n)(*[e._h for e in engines])
+        handle = ct.c_void_p()
+        e0._call(self._lib.tg_batch_create, arr, n, self._scratch.data_ptr(), ct.byref(handle))
+        self._h = handle
+
+    def new_histories(self, n_rows):
+        return [e.new_history(n_rows) for e in self.engines]
+
+    def step(self, n_steps, lr, histories=None, first_row=0):
+        n = len(self.engines)
+        arr = (ct.c_void_p * n)(*[h.data_ptr() for h in histories]) if histories is not None else None
+        self.engines[0]._call(self._lib.tg_batch_step, self._h, int(n_steps), float(lr), arr, int(first_row),
+                              tensors=tuple(histories or ()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.engines[0]._sync()
+            self._lib.tg_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _batch_key(m):
+    """Mappings with equal keys can share a tg_batch (the C library re-checks)."""
+    e = getattr(m, "_engine", None)
+    if type(m).__name__ != "Mapper" or e is None or getattr(m, "_sharded", None) is not None:
+        return None
+    c = e.cfg
+    if c.lambda_neighborhood_g1 or c.lambda_ct_islands or c.lambda_getis_ord or c.lambda_moran or c.lambda_geary:
+        return None
+    return (e.C, e.K, e.V, e.precision, bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device))
+
+
+def _train_batched(mappers, num_epochs, learning_rate):
+    batch = MapperBatch(mappers)
+    hists = batch.new_histories(max(int(num_epochs), 1))
+    batch.step(int(num_epochs), learning_rate, hists, 0)
+    out = []
+    for m, h in zip(mappers, hists):
+        P = m._engine.result().detach().cpu().numpy()
+        out.append((P, m._history_dict(h[:num_epochs])))
+    batch.close()
+    return out
+
+
+def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device="cuda:0", batched="auto", **train_kwargs):
+    """Train independent mappings together.
 
     builders: callables, each returning a `Mapper` / `MapperConstrained`.  They are called one after the other on the
               calling thread (the reference's initialisation draws from the global NumPy RNG, `np.random.seed(random_state)`,
-              which must not be interleaved), each under its own HIP stream so that the mapper binds to it; only the
-              training loops run concurrently.
+              which must not be interleaved).
+    batched:  "auto" (default): mappings that can share a `tg_batch` (Mapper, one shape, no spatial terms, no `val_each`)
+              advance in ONE launch per kernel; the others are trained one after the other.  False: one HIP stream + host
+              thread per mapping (`max_concurrent` at a time) for everything.
     Returns the list of `mapper.train(...)` results (in the order of `builders`) and the mappers themselves."""
     device = torch.device(device)
     builders = list(builders)
     n = len(builders)
-    results, mappers, streams = [None] * n, [None] * n, [None] * n
+    results, mappers = [None] * n, [None] * n
+    if batched and not train_kwargs.get("val_each"):
+        with (torch.cuda.device(device) if device.type == "cuda" else _null()):
+            for i in range(n):
+                mappers[i] = builders[i]()
+            groups = {}
+            for i, m in enumerate(mappers):
+                groups.setdefault(_batch_key(m) or ("single", i), []).append(i)
+            for key, idx in groups.items():
+                if key[0] != "single" and len(idx) > 1:
+                    for i, r in zip(idx, _train_batched([mappers[i] for i in idx], num_epochs, learning_rate)):
+                        results[i] = r
+                else:
+                    for i in idx:
+                        results[i] = mappers[i].train(num_epochs=num_epochs, learning_rate=learning_rate, print_each=None, **train_kwargs)
+        return results, mappers
+    streams = [None] * n
     with torch.cuda.device(device):
         for i in range(n):
             streams[i] = torch.cuda.Stream(device=device)
@@ -44,3 +131,11 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
         for f in [pool.submit(work, i) for i in range(n)]:
             f.result()
     return results, mappers
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -21,7 +21,10 @@ static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch,
     return 0;
 }
 static int tg_memset(void* dst, int v, size_t n, tg_stream_t) { memset(dst, v, n); return 0; }
+static int tg_memcpy_h2d(void* dst, const void* src, size_t n, tg_stream_t) { memcpy(dst, src, n); return 0; }
 static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t) { memcpy(dst, src, n); return 0; }
+#define TG_LAUNCH3(kern, gx, gy, gz, block, lds, stream, ...) \
+    hipsim::launch(hipsim::uint3s{(unsigned)(gx), (unsigned)(gy), (unsigned)(gz)}, hipsim::uint3s{(unsigned)(block), 1u, 1u}, [&] { kern(__VA_ARGS__); })
 static int tg_launch_error(const char** name) { *name = nullptr; return 0; }
 static bool tg_launch_failed() { return false; }
 static const char* tg_hip_errstr(int) { return "emulator"; }
@@ -45,6 +48,13 @@ static thread_local const char* g_launch_name = nullptr;
         const int _le = (int)hipGetLastError();                                                                                   \
         if (_le != 0 && g_launch_rc == 0) { g_launch_rc = _le; g_launch_name = #kern; }                                           \
     } while (0)
+#define TG_LAUNCH3(kern, gx, gy, gz, block, lds, stream, ...)                                                                      \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy), (unsigned)(gz)), dim3((unsigned)(block), 1, 1), (size_t)(lds), \
+                           stream, __VA_ARGS__);                                                                                  \
+        const int _le = (int)hipGetLastError();                                                                                   \
+        if (_le != 0 && g_launch_rc == 0) { g_launch_rc = _le; g_launch_name = #kern; }                                           \
+    } while (0)
 static int tg_launch_error(const char** name) {
     int e = g_launch_rc;
     *name = g_launch_name;
@@ -58,6 +68,9 @@ static int tg_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch,
     return (int)hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, s);
 }
 static int tg_memset(void* dst, int v, size_t n, tg_stream_t s) { return (int)hipMemsetAsync(dst, v, n, s); }
+static int tg_memcpy_h2d(void* dst, const void* src, size_t n, tg_stream_t s) {      // pageable source: staged before the call returns
+    return (int)hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s);
+}
 static int tg_memcpy(void* dst, const void* src, size_t n, tg_stream_t s) {
     return (int)hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
 }
@@ -309,6 +322,8 @@ static int tg_lds_attr() {
 #ifndef TG_SIM
     const int bytes = GE::LDS_BYTES;
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel_b<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel_b<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
 #define TG_BWD_ATTR(F, R, S) TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, F, R, S>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES))
     TG_BWD_ATTR(false, true, true); TG_BWD_ATTR(true, true, true); TG_BWD_ATTR(false, false, true); TG_BWD_ATTR(false, false, false);
 #undef TG_BWD_ATTR
@@ -611,10 +626,8 @@ static void tg_band_range(const TgLayout& L, int b, int* ct0, int* ct1, int* c0,
 }
 
 template <class PR>
-static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int band = -1,
-                             const unsigned char* St_alt = nullptr, bool unfiltered = false) {
+static TgFwdArgs tg_fwd_args(tg_mapper* m, int band, const unsigned char* St_alt, bool unfiltered, int* grid_out) {
     const TgLayout& L = m->L;
-    if (band < 0) stream = m->stream;
     TgFwdArgs a;
     a.M = (const float*)(m->st + L.s_M);
     a.rmax = m->fp(L.o_rshift);
@@ -635,18 +648,35 @@ static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int ban
         if (a.band_step_end > a.nsteps) a.band_step_end = a.nsteps;
         grid = tg_fwd_grid(L.nvt, L.nkt, 1);
     }
+    *grid_out = grid;
+    return a;
+}
+
+template <class PR>
+static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int band = -1,
+                             const unsigned char* St_alt = nullptr, bool unfiltered = false) {
+    const TgLayout& L = m->L;
+    if (band < 0) stream = m->stream;
+    int grid;
+    const TgFwdArgs a = tg_fwd_args<PR>(m, band, St_alt, unfiltered, &grid);
     if (L.T == 256) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoLarge>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
     else TG_LAUNCH((tg_fwd_kernel<PR, TgGeoSmall>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
     if (band < 0) tg_prof_mark(m, "tg_fwd_kernel");
     return TG_OK;
 }
 
-static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
+static TgGhatReduceArgs tg_ghat_args(tg_mapper* m, bool force_vox) {
     const TgLayout& L = m->L;
     TgGhatReduceArgs a;
     a.Gpart = m->fp(L.o_Gpart); a.nsplit = L.nsplit; a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
     a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat);
     a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = force_vox || (m->cfg.lambda_g2 != 0.f);
+    return a;
+}
+
+static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
+    const TgLayout& L = m->L;
+    const TgGhatReduceArgs a = tg_ghat_args(m, force_vox);
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
     TG_LAUNCH(tg_ghat_reduce, nrb, (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS, 256, 4 * 64 * 2 * 16, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
@@ -656,10 +686,9 @@ static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
     return TG_OK;
 }
 
-template <class PR>
-static int tg_launch_loss(tg_mapper* m, float* hist_row) {
+// arguments of the loss / gradient-coefficient stage: the statistics -> coefficient map (f) and the dGhat emitter (e)
+static void tg_loss_args(tg_mapper* m, float* hist_row, TgFinalizeArgs& f, TgEmitArgs& e) {
     const TgLayout& L = m->L;
-    TgFinalizeArgs f;
     f.genestat = m->fp(L.o_genestat); f.gnorm2 = m->fp(L.o_gnorm2); f.Ghat = m->fp(L.o_Ghat);
     f.voxstat = m->fp(L.o_voxstat); f.nky = (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS; f.vnorm2 = m->fp(L.o_vnorm2); f.d = m->fp(L.o_d);
     f.coef = m->fp(L.o_coef); f.vcoef = m->fp(L.o_vcoef);
@@ -673,15 +702,26 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.V;
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
     f.part_out = m->comm ? m->fp(L.o_rowpair) + 2 * (size_t)L.C : nullptr;       // spot shard: this rank's parts of the spot sums
-    TgEmitArgs e;
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
     e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) : nullptr;
     e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
     e.fin = f;
+}
+static bool tg_emit_self_ok(const tg_mapper* m) {      // the emit kernel can derive its coefficients itself (no spatial terms, LDS fits)
+    const TgLayout& L = m->L;
+    return !(L.has_nb || L.has_ct || L.has_ac) && L.bands == 1 && (L.Vtot == L.V || m->comm) && (size_t)(2 * L.Kp + 2 * TG_RB) * 4 <= 48 * 1024;
+}
+
+template <class PR>
+static int tg_launch_loss(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgFinalizeArgs f;
+    TgEmitArgs e;
+    tg_loss_args(m, hist_row, f, e);
     // Without spatial terms every gradient coefficient is a local function of the reduced statistics: the emit kernel
     // derives them itself and the scalars of the history row are left to one extra workgroup of the update kernel.
-    const bool self = !e.extra && L.bands == 1 && (L.Vtot == L.V || m->comm) && (size_t)(2 * L.Kp + 2 * TG_RB) * 4 <= 48 * 1024;
+    const bool self = tg_emit_self_ok(m);
     if (self) {
         m->fin_args = f; m->fin_pending = true;
         TG_LAUNCH((tg_dghat_emit<PR, false, true>), (L.V + TG_RB - 1) / TG_RB, 1, 256, (2 * L.Kp + 2 * TG_RB) * 4, m->stream, e);
@@ -704,7 +744,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
 // backward GEMM (X, row-dot partials) over the cell tiles [ct0, ct1) on `stream`; `x_only`: no row dots (they are
 // taken by tg_adam_rowpass)
 template <class PR>
-static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bool x_only = false) {
+static TgBwdArgs tg_bwd_args(tg_mapper* m, int ct0, int ct1, int* grid_out) {
     const TgLayout& L = m->L;
     TgBwdArgs a;
     a.dG = m->ws + L.o_dG;
@@ -723,7 +763,15 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
     else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, nct}; a.map_major_is_cells = 0; }
     else { a.map = TgTileMap{0, L.nvt, nct}; a.map_major_is_cells = 0; }
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
-    const int grid = tg_tilemap_grid(a.map);
+    *grid_out = tg_tilemap_grid(a.map);
+    return a;
+}
+
+template <class PR>
+static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bool x_only = false) {
+    const TgLayout& L = m->L;
+    int grid;
+    const TgBwdArgs a = tg_bwd_args<PR>(m, ct0, ct1, &grid);
     // (the cached-access variant exists for the single-GPU X-only epilogue only: the row-dot variants serve spot shards and
     //  very long rows, i.e. big problems, and every GEMM instantiation costs seconds of compile time)
 #define TG_BWD_GO(GE, F, R, S) TG_LAUNCH((tg_bwd_kernel<PR, GE, F, R, S>), grid, 1, GE::NT, GE::BWD_LDS_BYTES, stream, a)
@@ -909,6 +957,165 @@ static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool f
     m->step += 1;
     TG_LAUNCH_CK();
     return TG_OK;
+}
+
+// ---- batched independent mappings ------------------------------------------------------------------------------
+// B handles of ONE shape and configuration (cross-validation folds, seeds: utils.py:576-600, mapping_parameter_tuning.py:109-131)
+// advance together: one launch per kernel with blockIdx.z = mapping, the per-mapping kernel arguments in device arrays.
+struct tg_batch {
+    std::vector<tg_mapper*> h;
+    unsigned char* dev;                              // caller-provided scratch: the argument arrays
+    size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, total;
+    std::vector<float*> hist;                        // history base pointers the argument arrays currently hold
+    bool args_valid;
+};
+static size_t tg_batch_layout(int n, tg_batch* b) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
+    const size_t o_fwd = take(n * sizeof(TgFwdArgs)), o_ghat = take(n * sizeof(TgGhatReduceArgs)), o_gene = take(n * sizeof(TgGeneReduceArgs)),
+                 o_emit = take(n * sizeof(TgEmitArgs)), o_bwd = take(n * sizeof(TgBwdArgs)), o_upd = take(n * sizeof(TgUpdateArgs)),
+                 o_hreg = take(n * sizeof(TgHistRegArgs));
+    if (b) { b->o_fwd = o_fwd; b->o_ghat = o_ghat; b->o_gene = o_gene; b->o_emit = o_emit; b->o_bwd = o_bwd; b->o_upd = o_upd; b->o_hreg = o_hreg; b->total = off; }
+    return off;
+}
+extern "C" size_t tg_batch_query_bytes(int n_mappers) { return n_mappers > 0 ? tg_batch_layout(n_mappers, nullptr) : 0; }
+
+extern "C" int tg_batch_create(tg_mapper* const* mappers, int n, void* scratch_dev, tg_batch** out) {
+    if (!mappers || n < 1 || !scratch_dev || !out) return tg_fail(TG_ERR_INVALID, "null argument or empty batch");
+    const tg_mapper* m0 = mappers[0];
+    for (int i = 0; i < n; ++i) {
+        const tg_mapper* m = mappers[i];
+        if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper %d of the batch is not ready", i);
+        const TgLayout &A = m->L, &B = m0->L;
+        if (A.C != B.C || A.K != B.K || A.V != B.V || A.prec != B.prec || A.T != B.T || A.nsplit != B.nsplit || A.full != B.full)
+            return tg_fail(TG_ERR_INVALID, "mapper %d differs in shape / precision / terms from mapper 0 (a batch is B mappings of ONE shape)", i);
+        if (m->stream != m0->stream) return tg_fail(TG_ERR_INVALID, "all mappers of a batch must be created on the same stream");
+        if (m->step != m0->step) return tg_fail(TG_ERR_INVALID, "all mappers of a batch must be at the same step");
+        if (m->cfg.mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_UNSUPPORTED, "batches hold Mapper handles (MapperConstrained: use streams)");
+        if (m->comm || A.Vtot != A.V || A.bands > 1 || !tg_emit_self_ok(m) || A.V > TG_ROWPASS_MAX_V)
+            return tg_fail(TG_ERR_UNSUPPORTED, "mapper %d uses spatial terms, spot shards, the band pipeline or rows longer than %d spots", i, TG_ROWPASS_MAX_V);
+        if (m->cfg.beta1 != m0->cfg.beta1 || m->cfg.beta2 != m0->cfg.beta2) return tg_fail(TG_ERR_INVALID, "Adam betas differ inside the batch");
+        for (int j = 0; j < i; ++j) if (mappers[j] == m) return tg_fail(TG_ERR_INVALID, "mapper %d appears twice in the batch", i);
+    }
+    tg_batch* b = new (std::nothrow) tg_batch();
+    if (!b) return tg_fail(TG_ERR_INVALID, "out of host memory");
+    b->h.assign(mappers, mappers + n);
+    b->dev = (unsigned char*)scratch_dev;
+    tg_batch_layout(n, b);
+    b->args_valid = false;
+    *out = b;
+    return TG_OK;
+}
+extern "C" void tg_batch_destroy(tg_batch* b) { delete b; }
+
+template <class PR>
+static int tg_batch_upload(tg_batch* b, float* const* hist) {
+    const int n = (int)b->h.size();
+    std::vector<TgFwdArgs> fw(n); std::vector<TgGhatReduceArgs> gh(n); std::vector<TgGeneReduceArgs> gr(n);
+    std::vector<TgEmitArgs> em(n); std::vector<TgBwdArgs> bw(n); std::vector<TgUpdateArgs> up(n); std::vector<TgHistRegArgs> hr(n);
+    for (int i = 0; i < n; ++i) {
+        tg_mapper* m = b->h[i];
+        const TgLayout& L = m->L;
+        int grid;
+        fw[i] = tg_fwd_args<PR>(m, -1, nullptr, false, &grid);
+        gh[i] = tg_ghat_args(m, false);
+        gr[i] = TgGeneReduceArgs{m->fp(L.o_genepart), (L.V + TG_RB - 1) / TG_RB, L.Kp, m->fp(L.o_genestat)};
+        TgFinalizeArgs f;
+        tg_loss_args(m, nullptr, f, em[i]);
+        f.hist = hist ? hist[i] : nullptr;                      // BASE of the mapping's history (row offset: TgStepVar)
+        em[i].fin = f;
+        bw[i] = tg_bwd_args<PR>(m, 0, L.nct, &grid);
+        up[i] = tg_update_args(m, 0.f, true, 0, L.C);
+        up[i].fin = f; up[i].fin_on = 1;
+        hr[i] = TgHistRegArgs{m->fp(L.o_rowq), L.C, hist ? hist[i] : nullptr, m->cfg.lambda_r, m->cfg.lambda_l1, m->cfg.lambda_l2, 0};
+    }
+    tg_stream_t s = b->h[0]->stream;
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_fwd, fw.data(), n * sizeof(TgFwdArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_ghat, gh.data(), n * sizeof(TgGhatReduceArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_gene, gr.data(), n * sizeof(TgGeneReduceArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_emit, em.data(), n * sizeof(TgEmitArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_bwd, bw.data(), n * sizeof(TgBwdArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_upd, up.data(), n * sizeof(TgUpdateArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_hreg, hr.data(), n * sizeof(TgHistRegArgs), s));
+#ifndef TG_SIM
+    TG_CK(hipStreamSynchronize(s));        // (the host vectors go out of scope; once per tg_batch_step call, not per iteration)
+#endif
+    b->hist.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) b->hist[i] = hist ? hist[i] : nullptr;
+    b->args_valid = true;
+    return TG_OK;
+}
+
+template <bool FULL, bool X16>
+static void tg_launch_rowpass_b(const TgUpdateArgs* argv, TgStepVar var, int rows, int V, int nb, tg_stream_t stream) {
+#define TG_RPB(NQ, NT) TG_LAUNCH3((tg_adam_rowpass_b<FULL, X16, NQ, NT>), rows, 1, nb, NT, 256, stream, argv, var)
+    if (V <= 4096) {
+        const int nq = (V + 1023) / 1024;
+        if (nq <= 1) TG_RPB(1, 256); else if (nq <= 2) TG_RPB(2, 256); else TG_RPB(4, 256);
+    } else {
+        const int nq = (V + 2047) / 2048;
+        if (nq <= 3) TG_RPB(3, 512); else if (nq <= 4) TG_RPB(4, 512); else if (nq <= 5) TG_RPB(5, 512);
+        else if (nq <= 6) TG_RPB(6, 512); else TG_RPB(8, 512);
+    }
+#undef TG_RPB
+}
+
+template <class PR>
+static int tg_batch_step_impl(tg_batch* b, int n_steps, float lr, float* const* hist, int first_row) {
+    const int n = (int)b->h.size();
+    bool same = b->args_valid;
+    for (int i = 0; same && i < n; ++i) same = (b->hist[i] == (hist ? hist[i] : nullptr));
+    if (!same) { int rc = tg_batch_upload<PR>(b, hist); if (rc) return rc; }
+    tg_mapper* m0 = b->h[0];
+    const TgLayout& L = m0->L;
+    tg_stream_t s = m0->stream;
+    const int nrb = (L.V + TG_RB - 1) / TG_RB;
+    const bool x16 = (m0->cfg.precision == TG_PREC_BF16);
+    int gf, gb;
+    (void)tg_fwd_args<PR>(m0, -1, nullptr, false, &gf);
+    (void)tg_bwd_args<PR>(m0, 0, L.nct, &gb);
+    const TgFwdArgs* a_fwd = (const TgFwdArgs*)(b->dev + b->o_fwd);
+    const TgGhatReduceArgs* a_gh = (const TgGhatReduceArgs*)(b->dev + b->o_ghat);
+    const TgGeneReduceArgs* a_gr = (const TgGeneReduceArgs*)(b->dev + b->o_gene);
+    const TgEmitArgs* a_em = (const TgEmitArgs*)(b->dev + b->o_emit);
+    const TgBwdArgs* a_bw = (const TgBwdArgs*)(b->dev + b->o_bwd);
+    const TgUpdateArgs* a_up = (const TgUpdateArgs*)(b->dev + b->o_upd);
+    const TgHistRegArgs* a_hr = (const TgHistRegArgs*)(b->dev + b->o_hreg);
+    for (int it = 0; it < n_steps; ++it) {
+        if (L.T == 256) TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoLarge>), gf, 1, n, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, s, a_fwd);
+        else TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoSmall>), gf, 1, n, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, s, a_fwd);
+        TG_LAUNCH3(tg_ghat_reduce_b, nrb, (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS, n, 256, 4 * 64 * 2 * 16, s, a_gh);
+        TG_LAUNCH3(tg_gene_reduce_b, (L.Kp + 63) / 64, 1, n, 1024, TG_GR_GROUPS * 64 * 2 * 4, s, a_gr);
+        TG_LAUNCH3((tg_dghat_emit_b<PR>), nrb, 1, n, 256, (2 * L.Kp + 2 * TG_RB) * 4, s, a_em);
+        if (L.T == 256) TG_LAUNCH3((tg_bwd_kernel_b<PR, TgGeoLarge>), gb, 1, n, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, s, a_bw);
+        else TG_LAUNCH3((tg_bwd_kernel_b<PR, TgGeoSmall>), gb, 1, n, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, s, a_bw);
+        const double t = (double)(m0->step + 1);
+        TgStepVar var;
+        var.step_size = (float)((double)lr / (1.0 - pow((double)m0->cfg.beta1, t)));
+        var.bc2_sqrt = (float)sqrt(1.0 - pow((double)m0->cfg.beta2, t));
+        var.hist_row = hist ? (long long)(first_row + it) : -1;
+        if (L.full) { if (x16) tg_launch_rowpass_b<true, true>(a_up, var, L.C + 1, L.V, n, s); else tg_launch_rowpass_b<true, false>(a_up, var, L.C + 1, L.V, n, s); }
+        else { if (x16) tg_launch_rowpass_b<false, true>(a_up, var, L.C + 1, L.V, n, s); else tg_launch_rowpass_b<false, false>(a_up, var, L.C + 1, L.V, n, s); }
+        if (L.full) TG_LAUNCH3(tg_hist_regs_b, 1, 1, n, 1024, 64, s, a_hr, var);
+        for (int i = 0; i < n; ++i) b->h[i]->step += 1;
+        if (tg_launch_failed()) return tg_launch_status();
+    }
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
+
+extern "C" int tg_batch_step(tg_batch* b, int n_steps, float lr, float* const* history_dev, int first_row) {
+    if (!b || b->h.empty()) return tg_fail(TG_ERR_STATE, "empty batch");
+    if (n_steps < 0 || first_row < 0) return tg_fail(TG_ERR_INVALID, "n_steps < 0 or first_row < 0");
+    for (size_t i = 0; i < b->h.size(); ++i) {
+        if (b->h[i]->step != b->h[0]->step) return tg_fail(TG_ERR_STATE, "the mappers of the batch are at different steps (one was stepped on its own)");
+        b->h[i]->fin_pending = false;
+    }
+    switch (b->h[0]->cfg.precision) {
+        case TG_PREC_F32: return tg_batch_step_impl<PrecF32>(b, n_steps, lr, history_dev, first_row);
+        case TG_PREC_BF16: return tg_batch_step_impl<PrecBF16>(b, n_steps, lr, history_dev, first_row);
+        default: return tg_batch_step_impl<PrecBF16x3>(b, n_steps, lr, history_dev, first_row);
+    }
 }
 
 // ---- spot-sharded multi-GPU path --------------------------------------------------------------------------------------

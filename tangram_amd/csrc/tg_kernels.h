@@ -226,7 +226,7 @@ TG_HD bool tg_fwd_map(int b, int nvt, int nkt, int nsplit, int& vt, int& kt, int
 }
 
 template <class PR, class GE>
-TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) {
+TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
@@ -417,7 +417,7 @@ struct TgGhatReduceArgs {
 
 // One workgroup = 16 spots x 256 genes: wave w owns 4 of the spot rows, lane q one float4 of genes.  (The earlier layout,
 // 16 rows x all genes per workgroup, left a V = 1250 spot shard with 79 workgroups to stream 12 partial copies of Ghat.)
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) {
+TG_DEV void tg_ghat_reduce_body(const TgGhatReduceArgs& a) {
     TG_LDS_DECL;
     f32x4* red = (f32x4*)tg_lds;     // [4 row groups][64 lanes][2]
     const int t = threadIdx.x, q = t & 63, rg = t >> 6;
@@ -472,7 +472,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) {
 // K2b: second stage of the per-gene sums (fixed order => deterministic): 64 genes x 16 partial groups per block.
 // (A latency-bound kernel: every thread walks nrb / 16 row blocks; with 4 groups it took 29 us at 600 row blocks.)
 #define TG_GR_GROUPS 16
-TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
+TG_DEV void tg_gene_reduce_body(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;        // [TG_GR_GROUPS][64][2]
     const int kx = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -693,7 +693,7 @@ struct TgEmitArgs {
 // dependent latency) then no longer sits between the forward and the backward GEMM: the scalars of the history row are
 // produced by one extra workgroup of the update kernel, off the critical path.  dynamic LDS: (2 Kp + 2 TG_RB) floats.
 template <class PR, bool EXTRA, bool SELF>
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) {
+TG_DEV void tg_dghat_emit_body(const TgEmitArgs& a) {
     TG_LDS_DECL;
     float* cf = (float*)tg_lds;                          // SELF: [2][Kp] alpha, beta; then [2][TG_RB] va, vb
     constexpr int NQ = PR::CH / 4;                       // float4 groups per operand chunk
@@ -776,7 +776,7 @@ struct TgBwdArgs {
 enum { TGP1_R = 0, TGP1_ENT, TGP1_L1, TGP1_L2, TGP1_Q, TGP1_PA, TGP1_N };
 
 template <class PR, class GE, bool FULL, bool ROWDOT, bool STREAM>
-TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) {
+TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
@@ -1333,7 +1333,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
 //   pass 2: dM = P (dP - r_c), Adam, stores, (max, sum exp) of the new row.
 // HBM traffic is that of tg_adam_update; tg_bwd_kernel no longer reads M nor writes row-dot partials.
 template <bool FULL, bool X16, int NQ, int NT, bool STREAM>
-TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(TgUpdateArgs a) {
+TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [NW waves][TGP1_N] then [NW][2]
     constexpr int NW = NT / 64;
@@ -1502,7 +1502,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
 // entropy / L1 / L2 scalars (mapping_optimizer.py:224-231) from the per-row sums -> history row
 struct TgHistRegArgs { const float* rowq; int C; float* hist; float lambda_r, lambda_l1, lambda_l2; int constrained; };
 
-TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs(TgHistRegArgs a) {
+TG_DEV void tg_hist_regs_body(const TgHistRegArgs& a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;
     float e = 0.f, l1 = 0.f, l2 = 0.f;
@@ -1522,6 +1522,48 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs(TgHistRegArgs a) {
         if (a.lambda_l2 != 0.f) { a.hist[TGH_L2] = l2; total += a.lambda_l2 * l2; }
         a.hist[TGH_TOTAL] = total;
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Kernel entry points of the iteration.  Every kernel of the single-GPU Mapper step exists twice: with its arguments by value
+// (one mapping per launch) and as `_b` (BATCHED): the arguments of B independent mappings of one shape sit in an
+// array in device memory, blockIdx.z picks the mapping -- B cross-validation folds / seeds advance in ONE launch per kernel
+// instead of B (clusters-mode problems, 18 x 250 x 9852, are launch-bound: one fold leaves > 90 % of the chip idle).
+// ----------------------------------------------------------------------------------------------
+struct TgGeneReduceArgs { const float* genepart; int nrb, Kp; float* genestat; };
+// what changes from step to step in a batch (everything else is constant per mapping and lives in the argument arrays)
+struct TgStepVar { float step_size, bc2_sqrt; long long hist_row; };    // hist_row < 0: no history wanted
+
+template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) { tg_fwd_body<PR, GE>(a); }
+template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel_b(const TgFwdArgs* argv) { tg_fwd_body<PR, GE>(argv[blockIdx.z]); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) { tg_ghat_reduce_body(a); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce_b(const TgGhatReduceArgs* argv) { tg_ghat_reduce_body(argv[blockIdx.z]); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body(genepart, nrb, Kp, genestat); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_b(const TgGeneReduceArgs* argv) {
+    const TgGeneReduceArgs a = argv[blockIdx.z];
+    tg_gene_reduce_body(a.genepart, a.nrb, a.Kp, a.genestat);
+}
+template <class PR, bool EXTRA, bool SELF> TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) { tg_dghat_emit_body<PR, EXTRA, SELF>(a); }
+template <class PR> TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit_b(const TgEmitArgs* argv) { tg_dghat_emit_body<PR, false, true>(argv[blockIdx.z]); }
+template <class PR, class GE, bool FULL, bool ROWDOT, bool STREAM>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel(TgBwdArgs a) { tg_bwd_body<PR, GE, FULL, ROWDOT, STREAM>(a); }
+template <class PR, class GE>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel_b(const TgBwdArgs* argv) { tg_bwd_body<PR, GE, false, false, false>(argv[blockIdx.z]); }
+template <bool FULL, bool X16, int NQ, int NT, bool STREAM>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(TgUpdateArgs a) { tg_adam_rowpass_body<FULL, X16, NQ, NT, STREAM>(a); }
+template <bool FULL, bool X16, int NQ, int NT>
+TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass_b(const TgUpdateArgs* argv, TgStepVar var) {
+    TgUpdateArgs a = argv[blockIdx.z];
+    a.step_size = var.step_size; a.bc2_sqrt = var.bc2_sqrt;
+    a.fin.hist = (var.hist_row >= 0 && a.fin.hist) ? a.fin.hist + var.hist_row * TGH_NTERMS : a.fin.coef;   // (no history: the row lands in the
+    tg_adam_rowpass_body<FULL, X16, NQ, NT, false>(a);                                                     //  unused coefficient scratch)
+}
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs(TgHistRegArgs a) { tg_hist_regs_body(a); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_hist_regs_b(const TgHistRegArgs* argv, TgStepVar var) {
+    TgHistRegArgs a = argv[blockIdx.z];
+    if (var.hist_row < 0 || !a.hist) return;
+    a.hist += var.hist_row * TGH_NTERMS;
+    tg_hist_regs_body(a);
 }
 
 // ----------------------------------------------------------------------------------------------

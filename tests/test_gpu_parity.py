@@ -276,8 +276,9 @@ def test_update_kernel_row_lengths(V, variant):
 
 
 def test_concurrent_mappings_bit_identical():
-    """tangram_amd.train_many: independent mappings on separate HIP streams and host threads must give the very
-    bits of the same mappings trained one after the other (handles share nothing), for Mapper and MapperConstrained."""
+    """tangram_amd.train_many: independent mappings -- the five Mapper folds advance as ONE tg_batch (one launch per
+    kernel, blockIdx.z = fold), the MapperConstrained ones on their own; then everything on separate HIP streams and host
+    threads -- must give the very bits of the same mappings trained one after the other (handles share nothing)."""
     import tangram_amd as tg
     import tangram_amd.mapping_optimizer as mo
     from oracle import tangram_oracle as orc
@@ -295,14 +296,30 @@ def test_concurrent_mappings_bit_identical():
 
     builders = [cells(i) for i in range(5)] + [constrained(i) for i in range(3)]
     seq = [b().train(num_epochs=120, learning_rate=0.1, print_each=None) for b in builders]
-    res, mappers = tg.train_many(builders, 120, 0.1, max_concurrent=4, device=DEV)
-    assert len(res) == len(seq) == len(mappers)
-    for a, b in zip(seq, res):
-        assert len(a) == len(b)
-        np.testing.assert_array_equal(a[0], b[0])
-        if len(a) == 3:
-            np.testing.assert_array_equal(a[1], b[1])
-        assert list(a[-1]["main_loss"]) == list(b[-1]["main_loss"])
+    for kw in (dict(batched="auto"), dict(batched=False, max_concurrent=4)):
+        res, mappers = tg.train_many(builders, 120, 0.1, device=DEV, **kw)
+        assert len(res) == len(seq) == len(mappers)
+        for a, b in zip(seq, res):
+            assert len(a) == len(b)
+            np.testing.assert_array_equal(a[0], b[0])
+            if len(a) == 3:
+                np.testing.assert_array_equal(a[1], b[1])
+            assert list(a[-1]["main_loss"]) == list(b[-1]["main_loss"])
+        for m in mappers:
+            m.release()
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
+def test_batched_mappings(precision):
+    """tg_batch on the GPU: 8 leave-one-gene-out folds of a clusters-mode shape in one launch per kernel, every fold against the
+    fp64 oracle and bit-identical to the fold trained alone; also a shape that takes the 256^2 tiles and several forward splits."""
+    from tests.test_batched import check_batched
+    tol = pc.TOL[precision]
+    check_batched(DEV, precision, C=18, K=60, V=1300, B=8, epochs=12, lam=dict(lambda_d=1, lambda_g1=1, lambda_g2=0.5),
+                  tol_loss=tol["loss"], tol_P=tol["P"])
+    if precision == "bf16x3":
+        check_batched(DEV, precision, C=4200, K=40, V=1100, B=3, epochs=4, lam=dict(lambda_d=1, lambda_g1=1, lambda_r=1e-3),
+                      tol_loss=tol["loss"], tol_P=tol["P"])
 
 
 @pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "bf16x3"), (4, "bf16x3")])
