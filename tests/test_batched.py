@@ -45,8 +45,9 @@ def check_batched(device, precision, C, K, V, B, epochs, lam, tol_loss, tol_P):
         o = orc.OracleMapper(M0=orc.reference_init_M(C, V, seed), dtype=np.float64, **kw)
         Po, ho = o.train(epochs, 0.1)
         for k in ("total_loss", "main_loss", "kl_reg"):
-            err = np.abs(np.array([float(x) for x in hist[k]]) - np.array(ho[k])).max()
-            assert err <= tol_loss, (i, k, err)
+            ref = np.array(ho[k], dtype=np.float64)
+            err = np.abs(np.array([float(x) for x in hist[k]]) - ref).max()
+            assert err <= tol_loss * max(1.0, np.abs(ref).max()), (i, k, err)      # (lambda_r * entropy puts total_loss at ~30)
         assert np.abs(P - Po).max() <= tol_P, i
     # the handles remain usable on their own afterwards (same step count everywhere)
     assert len({m._engine.logits()[3] for m in mappers}) == 1
