@@ -1,6 +1,6 @@
 """Builds profiles/pmc_traffic.json from the per-group summaries that scripts/gpu_pmc.sh leaves under
 profiles/r01/<pmc dir>/g*/**/*summary.txt (rocprofv3 --pmc passes of bench.py, averaged per dispatch).
-usage: make_pmc_traffic.py precision=dir [precision=dir ...]"""
+usage: make_pmc_traffic.py precision=dir [precision=dir ...]      (round 2: bf16x3=profiles/r02/pmc_bf16x3)"""
 import glob
 import json
 import os
