@@ -108,6 +108,9 @@ extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 #define TG_MAX_BANDS 16
+#ifndef TG_FWD_WIDE
+#define TG_FWD_WIDE 1                                 // forward GEMM on 128 x 512 tiles where the 256^2 geometry would be used and Kp % 512 == 0
+#endif
 struct TgLayout {
     int C, K, V, Vtot, Kp, Vp, Vr, Cp, Cr, nvt, nct, nkt, nrb, nsplit, ESZ, BKE, prec, full, T;
     size_t o_Sk, o_St, o_StP, o_dG, o_Gp, o_Ghat, o_Gpart, o_genepart, o_genestat, o_gnorm2, o_voxstat, o_vnorm2,
@@ -116,6 +119,7 @@ struct TgLayout {
         o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
         o_accmpart, o_accm, o_actnorm, total;
     int T_ct, Tp, has_nb, has_ct, has_ac, bands, nranks;
+    int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
     size_t o_gathered, pair_stride;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
@@ -172,6 +176,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->Cp = (int)rup(L->C, 64);
     L->Cr = (int)rup(L->C, L->T);
     L->nvt = L->Vr / L->T; L->nct = L->Cr / L->T; L->nkt = L->Kp / L->T;
+    L->fwd_wide = (TG_FWD_WIDE && L->T == 256 && L->Kp % 512 == 0 && cfg->precision == TG_PREC_BF16X3) ? 1 : 0;   // (measured: plain bf16 is faster on 256^2, profiles/r02/run8_wide)
     L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
@@ -323,6 +328,10 @@ static int tg_lds_attr() {
     const int bytes = GE::LDS_BYTES;
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel_b<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if constexpr (GE::TM == 256 && PR::NP == 2) {
+        TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel<PR, TgGeoWide>, hipFuncAttributeMaxDynamicSharedMemorySize, TgGeoWide::LDS_BYTES));
+        TG_CK(hipFuncSetAttribute((const void*)tg_fwd_kernel_b<PR, TgGeoWide>, hipFuncAttributeMaxDynamicSharedMemorySize, TgGeoWide::LDS_BYTES));
+    }
     TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel_b<PR, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES));
 #define TG_BWD_ATTR(F, R, S) TG_CK(hipFuncSetAttribute((const void*)tg_bwd_kernel<PR, GE, F, R, S>, hipFuncAttributeMaxDynamicSharedMemorySize, GE::BWD_LDS_BYTES))
     TG_BWD_ATTR(false, true, true); TG_BWD_ATTR(true, true, true); TG_BWD_ATTR(false, false, true); TG_BWD_ATTR(false, false, false);
@@ -636,9 +645,10 @@ static TgFwdArgs tg_fwd_args(tg_mapper* m, int band, const unsigned char* St_alt
     a.St = St_alt ? St_alt : m->ws + L.o_St;
     a.Gpart = m->fp(L.o_Gpart);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
-    a.nkt = L.nkt; a.nvt = L.nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
+    const int nvt = L.fwd_wide ? L.Vr / 128 : L.nvt, nkt = L.fwd_wide ? L.Kp / 512 : L.nkt;
+    a.nkt = nkt; a.nvt = nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
     a.band_index = 0; a.band_step_begin = 0; a.band_step_end = 0;
-    int grid = tg_fwd_grid(L.nvt, L.nkt, L.nsplit);
+    int grid = tg_fwd_grid(nvt, nkt, L.nsplit);
     if (band >= 0) {
         int ct0, ct1, c0, c1;
         tg_band_range(L, band, &ct0, &ct1, &c0, &c1);
@@ -646,7 +656,7 @@ static TgFwdArgs tg_fwd_args(tg_mapper* m, int band, const unsigned char* St_alt
         a.band_step_begin = c0 / PR::BKE;
         a.band_step_end = (band == L.bands - 1) ? a.nsteps : (ct1 * L.T) / PR::BKE;
         if (a.band_step_end > a.nsteps) a.band_step_end = a.nsteps;
-        grid = tg_fwd_grid(L.nvt, L.nkt, 1);
+        grid = tg_fwd_grid(nvt, nkt, 1);
     }
     *grid_out = grid;
     return a;
@@ -659,7 +669,9 @@ static int tg_launch_forward(tg_mapper* m, tg_stream_t stream = nullptr, int ban
     if (band < 0) stream = m->stream;
     int grid;
     const TgFwdArgs a = tg_fwd_args<PR>(m, band, St_alt, unfiltered, &grid);
-    if (L.T == 256) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoLarge>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
+    if (L.fwd_wide) {
+        if constexpr (PR::NP == 2) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoWide>), grid, 1, TgGeoWide::NT, TgGeoWide::LDS_BYTES, stream, a);
+    } else if (L.T == 256) TG_LAUNCH((tg_fwd_kernel<PR, TgGeoLarge>), grid, 1, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, stream, a);
     else TG_LAUNCH((tg_fwd_kernel<PR, TgGeoSmall>), grid, 1, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, stream, a);
     if (band < 0) tg_prof_mark(m, "tg_fwd_kernel");
     return TG_OK;
@@ -1082,7 +1094,9 @@ static int tg_batch_step_impl(tg_batch* b, int n_steps, float lr, float* const* 
     const TgUpdateArgs* a_up = (const TgUpdateArgs*)(b->dev + b->o_upd);
     const TgHistRegArgs* a_hr = (const TgHistRegArgs*)(b->dev + b->o_hreg);
     for (int it = 0; it < n_steps; ++it) {
-        if (L.T == 256) TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoLarge>), gf, 1, n, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, s, a_fwd);
+        if (L.fwd_wide) {
+            if constexpr (PR::NP == 2) TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoWide>), gf, 1, n, TgGeoWide::NT, TgGeoWide::LDS_BYTES, s, a_fwd);
+        } else if (L.T == 256) TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoLarge>), gf, 1, n, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, s, a_fwd);
         else TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoSmall>), gf, 1, n, TgGeoSmall::NT, TgGeoSmall::LDS_BYTES, s, a_fwd);
         TG_LAUNCH3(tg_ghat_reduce_b, nrb, (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS, n, 256, 4 * 64 * 2 * 16, s, a_gh);
         TG_LAUNCH3(tg_gene_reduce_b, (L.Kp + 63) / 64, 1, n, 1024, TG_GR_GROUPS * 64 * 2 * 4, s, a_gr);

@@ -71,11 +71,15 @@ struct TgGeo {
     static constexpr int STAGE_BYTES = STAGE_CHUNKS * 16, LDS_BYTES = 2 * STAGE_BYTES;
     static constexpr int BWD_LDS_BYTES = LDS_BYTES + TN * 16;            // + the per-cell constants of the row-dot epilogue
     static constexpr int LA = A_CHUNKS / NT, LB = B_CHUNKS / NT;       // 16-byte loads per thread per stage
-    static_assert(NT == 2 * TM, "forward A staging assumes (TM/4 spot quads) x 8 chunk slots == NT threads");
+    static_assert(NT >= 2 * TM && NT % (2 * TM) == 0, "forward A staging: (TM/4 spot quads) x 8 chunk slots threads stage, the rest only multiply");
     static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0 && FM % 4 == 0, "tile / thread mismatch");
 };
 typedef TgGeo<128, 128, 2, 2> TgGeoSmall;
 typedef TgGeo<256, 256, 2, 4> TgGeoLarge;
+// forward only: 128 spots x 512 genes, 8 waves side by side along the genes (the per-wave fragment grid of TgGeoLarge).  The
+// softmax staging of an M panel is redone by every gene tile that shares it: 2 instead of 4 times at K = 1000.  Two stages of
+// 80 KB = the whole 160 KB of LDS.
+typedef TgGeo<128, 512, 1, 8> TgGeoWide;
 
 // One contraction step of the workgroup tile: software-pipelined over (k-chunk group q) x (blocks of GA A-fragments):
 // the ds_read_b128 of the NEXT block are issued before the MFMAs of the current one, so that the LDS latency is
@@ -254,7 +258,8 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     //   bf16x3      : slot = HALF a k-chunk (4 cells): the thread writes 8 bytes of the hi chunk and 8 bytes of the lo chunk,
     //                 so that every exponential is evaluated exactly once.
     constexpr int RS = (PR::NP == 2) ? PR::CH / 2 : PR::CH;
-    const int quad = t % (GE::TM / 4), slot = t / (GE::TM / 4);
+    const int quad = t % (GE::TM / 4), slot = (t / (GE::TM / 4)) & 7;
+    const bool stager = t < 2 * GE::TM;                        // (wide geometry: waves 4-7 only multiply; wave-uniform)
     const int kc = (PR::NP == 2) ? (slot >> 1) : slot;         // k-chunk of the 128-byte step row
     const int half = (PR::NP == 2) ? (slot & 1) : 0;
     const int vcol = v0 + 4 * quad;
@@ -269,11 +274,13 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     const size_t bpitch = (size_t)a.nsteps * 128;
 
     auto load_m = [&](int step, int j) {                       // one float4 row of the M micro-block of `step`
+        if (!stager) return;
         const int c = step * PR::BKE + kc * PR::CH + half * RS + j;
         const int cc = c < a.C ? c : a.C - 1;
         mreg[j] = *(const f32x4*)(a.M + (size_t)cc * a.Vp + vload);
     };
     auto load_sh = [&](int step) {
+        if (!stager) return;
         const int cb = step * PR::BKE + kc * PR::CH + half * RS;
 #pragma unroll
         for (int j = 0; j < RS; ++j) {
@@ -342,6 +349,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
         }
     };
     auto store_stage = [&](u32x4* st) {
+        if (!stager) return;
         if (PR::NP == 2 && full_tile) store_stage_impl(st, std::false_type());     // (the second copy only pays off for bf16x3)
         else store_stage_impl(st, std::true_type());
     };

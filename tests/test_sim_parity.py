@@ -53,12 +53,14 @@ def test_emulated_forward_splits_agree(sim):
         assert np.linalg.norm(o - ref) / np.linalg.norm(ref) < 1e-6
 
 
+@pytest.mark.parametrize("K", [24, 290])
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
-def test_emulated_large_tile_geometry(sim, precision):
-    """Force the 256 x 256 / 512-thread geometry on a small ragged problem and compare one step with the oracle."""
+def test_emulated_large_tile_geometry(sim, precision, K):
+    """Force the 256 x 256 / 512-thread geometry on a small ragged problem and compare one step with the oracle.
+    K = 290 pads to 512 gene columns: the bf16 / bf16x3 forward then runs on the 128 x 512 tiles (TgGeoWide)."""
     from tangram_amd.engine import HipMapperEngine
     from oracle import tangram_oracle as orc
-    C, K, V = 300, 24, 270            # 2 x 2 tiles of 256, ragged
+    C, V = 300, 270                   # 2 x 2 tiles of 256, ragged
     data = orc.make_synthetic(C, K, V, seed=9)
     M0 = orc.reference_init_M(C, V, 4)
     lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_r=1e-3)
