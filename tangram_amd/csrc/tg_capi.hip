@@ -1542,3 +1542,12 @@ extern "C" int tg_debug_fwd_map(int nvt, int nkt, int nsplit, int b, int* vt, in
     if (b < 0) return tg_fwd_grid(nvt, nkt, nsplit);
     return tg_fwd_map(b, nvt, nkt, nsplit, *vt, *kt, *split) ? 1 : 0;
 }
+// the launch geometry tg_make_layout derives from a configuration: out[0..7] = tile edge, cell tiles, spot tiles, gene tiles,
+// forward splits, forward on 128 x 512 tiles (0/1), cell bands, 0
+extern "C" int tg_debug_layout(const tg_config* cfg, int* out) {
+    TgLayout L;
+    const int rc = tg_make_layout(cfg, &L);
+    if (rc != TG_OK) return rc;
+    out[0] = L.T; out[1] = L.nct; out[2] = L.nvt; out[3] = L.nkt; out[4] = L.nsplit; out[5] = L.fwd_wide; out[6] = L.bands; out[7] = 0;
+    return TG_OK;
+}

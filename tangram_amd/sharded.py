@@ -194,7 +194,7 @@ class ShardedMapperEngine:
 
 
 def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapper", precision="bf16x3", lambdas=None,
-                 target_count=0.0, group=None, fwd_splits=0, comm=None, transport="auto"):
+                 target_count=0.0, group=None, fwd_splits=0, tile_size=0, comm=None, transport="auto"):
     """Slice full problem arrays (identical on every rank) into this rank's spot block."""
     pc = comm if comm is not None else DistComm(group)
     world, rank = pc.world, pc.rank
@@ -210,5 +210,5 @@ def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapp
         M_l = M_l.contiguous()
     d_l = None if d is None else d[lo:hi]
     return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, F0, n_spots_total=V, device=device, mode=mode, precision=precision,
-                               lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, comm=comm,
-                               transport=transport)
+                               lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, tile_size=tile_size,
+                               comm=comm, transport=transport)

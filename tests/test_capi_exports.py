@@ -90,3 +90,26 @@ def test_forward_grid_map_is_a_bijection(nvt, nkt, nsplit):
             assert key not in seen and a.value < nvt and b_.value < nkt and c.value < nsplit
             seen.add(key)
     assert len(seen) == nvt * nkt * nsplit
+
+
+def test_launch_geometry_of_the_baseline_shapes():
+    """tg_make_layout on the host: cfg2 takes 256^2 tiles and, for split-bf16, the 128 x 512 forward tiles."""
+    from tangram_amd import _build, _capi
+    lib = ctypes.CDLL(_build.build())
+    out = (ctypes.c_int * 8)()
+
+    def geo(C, K, V, prec, v_total=0, ranks=0):
+        cfg = _capi.TgConfig()
+        cfg.abi_version = _capi.TG_ABI_VERSION
+        cfg.n_cells, cfg.n_genes, cfg.n_spots, cfg.n_spots_total, cfg.n_ranks = C, K, V, v_total, ranks
+        cfg.lambda_g1, cfg.has_density, cfg.lambda_d, cfg.precision = 1.0, 1, 1.0, prec
+        assert lib.tg_debug_layout(ctypes.byref(cfg), out) == 0
+        return list(out)
+
+    T, nct, nvt, nkt, nsplit, wide, bands, _ = geo(30000, 1000, 10000, 2)
+    assert (T, nct, nvt, nkt, wide, bands) == (256, 118, 40, 4, 1, 1)
+    assert geo(30000, 1000, 10000, 1)[5] == 0            # plain bf16 keeps the 256^2 forward
+    assert geo(30000, 1000, 10000, 0)[5] == 0            # and so does exact fp32
+    assert geo(30000, 1000, 1250, 2, v_total=10000, ranks=8)[:3] == [256, 118, 5]
+    assert geo(30000, 700, 10000, 2)[5] == 0             # 701 gene columns pad to 768: not a multiple of 512
+    assert geo(2000, 100, 500, 2)[0] == 128

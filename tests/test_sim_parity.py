@@ -2,6 +2,8 @@
 container has no GPU): index arithmetic, masking, barriers, launch sequence and host logic are
 checked against fixtures generated from the unmodified reference.  The GPU parity tests proper
 are tests/test_gpu_parity.py (-m gpu)."""
+import ctypes as ct
+
 import numpy as np
 import pytest
 
@@ -65,6 +67,9 @@ def test_emulated_large_tile_geometry(sim, precision, K):
     M0 = orc.reference_init_M(C, V, 4)
     lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_r=1e-3)
     e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision=precision, lambdas=lam, tile_size=256)
+    geo = (ct.c_int * 8)()
+    assert e._lib.tg_debug_layout(ct.byref(e.cfg), geo) == 0
+    assert geo[0] == 256 and geo[5] == int(K == 290 and precision == "bf16x3")
     n = 2
     hist = e.new_history(n)
     e.step(n, 0.1, hist)
