@@ -236,7 +236,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
 #if TG_YOUNG_PRIO && !defined(TG_SIM)
-    if (wave >= GE::NT / 128) __builtin_amdgcn_s_setprio(1);
+    if (TG_YOUNG_PRIO == 1 ? (wave >= GE::NT / 128) : (wave < GE::NT / 128)) __builtin_amdgcn_s_setprio(TG_YOUNG_PRIO >= 3 ? 3 : 1);
 #endif
     int vt, kt, split;
     const bool band = a.band_step_end > 0;
@@ -274,6 +274,9 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     const size_t bpitch = (size_t)a.nsteps * 128;
 
     auto load_m = [&](int step, int j) {                       // one float4 row of the M micro-block of `step`
+#if defined(TG_ABL_FWD) && TG_ABL_FWD >= 2
+        return;
+#endif
         if (!stager) return;
         const int c = step * PR::BKE + kc * PR::CH + half * RS + j;
         const int cc = c < a.C ? c : a.C - 1;
@@ -350,6 +353,16 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     };
     auto store_stage = [&](u32x4* st) {
         if (!stager) return;
+#if defined(TG_ABL_FWD) && TG_ABL_FWD >= 1      // experiment (wrong results): the forward without the arithmetic of its softmax staging
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * quad + i;
+            if constexpr (PR::NP == 2) {
+                ((u32x2*)(st + row * 8 + tg_swz(row, kc)))[half] = u32x2{0x38003800u, 0x38003800u};
+                ((u32x2*)(st + row * 8 + tg_swz(row, 4 + kc)))[half] = u32x2{0u, 0u};
+            } else st[row * 8 + tg_swz(row, slot)] = u32x4{0x38003800u, 0x38003800u, 0x38003800u, 0x38003800u};
+        }
+        return;
+#endif
         if (PR::NP == 2 && full_tile) store_stage_impl(st, std::false_type());     // (the second copy only pays off for bf16x3)
         else store_stage_impl(st, std::true_type());
     };
