@@ -120,6 +120,7 @@ struct TgLayout {
         o_accmpart, o_accm, o_actnorm, total;
     int T_ct, Tp, has_nb, has_ct, has_ac, bands, nranks;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
+    int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_tune_bwd)
     size_t o_gathered, pair_stride;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
@@ -157,7 +158,10 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->BKE = cfg->precision == TG_PREC_BF16 ? 64 : 32;     // contraction elements per 128-byte step
     if (cfg->tile_size != 0 && cfg->tile_size != 128 && cfg->tile_size != 256) return tg_fail(TG_ERR_INVALID, "tile_size must be 0, 128 or 256");
     // large geometry (256 x 256 tiles, one 512-thread workgroup per CU) once every tile axis is long enough to fill the chip
-    L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 1024) ? 256 : 128);
+    // (measured, profiles/r02/run10_tiles: 30k x 1k x 500 and x 1000 are 8 - 11 % faster on 256 tiles, 20k x 1k x 324 is 14 % faster on
+    //  128: there the spots pad to 512 instead of 384)
+    const bool pad_ok = rup((size_t)L->V, 256) * 100 <= rup((size_t)L->V, 128) * 115;
+    L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 448 && pad_ok) ? 256 : 128);
     L->has_nb = cfg->lambda_neighborhood_g1 > 0.f;
     L->has_ct = cfg->lambda_ct_islands > 0.f;
     L->has_ac = cfg->lambda_getis_ord > 0.f || cfg->lambda_moran > 0.f || cfg->lambda_geary > 0.f;
@@ -177,6 +181,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->Cr = (int)rup(L->C, L->T);
     L->nvt = L->Vr / L->T; L->nct = L->Cr / L->T; L->nkt = L->Kp / L->T;
     L->fwd_wide = (TG_FWD_WIDE && L->T == 256 && L->Kp % 512 == 0 && cfg->precision == TG_PREC_BF16X3) ? 1 : 0;   // (measured: plain bf16 is faster on 256^2, profiles/r02/run8_wide)
+    L->bwd_T = L->T;
     L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
@@ -217,7 +222,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_fgate = take((size_t)L->Cp * 4);
     L->o_densw = take((size_t)L->Cp * 4);
     const size_t np1 = L->full ? TGP1_N : 1;
-    L->o_part = take((size_t)L->nvt * np1 * L->C * 4);
+    L->o_part = take((size_t)(L->Vr / 128) * np1 * L->C * 4);      // (one partial per spot tile of the backward GEMM, 128 or 256 wide)
     L->o_rowq = take((size_t)TGP1_N * L->C * 4);
     L->pair_stride = (size_t)2 * L->C + TG_PAIR_TAIL;     // (max, sum exp) pairs + the per-rank history partials
     L->o_rowpair = take(L->pair_stride * 4);
@@ -292,6 +297,7 @@ struct tg_mapper {
     // history scalars deferred from tg_launch_loss to one extra workgroup of the next update kernel (tg_dghat_emit<SELF>)
     bool stream_once;                                // the per-iteration arrays exceed the MALL: non-temporal accesses (tg_ld_stream)
     bool fin_pending;
+    bool bwd_tuned;                                  // tg_tune_bwd has run
     TgFinalizeArgs fin_args;
     tg_comm* comm;                                   // spot-sharded run: the communicator (borrowed), else null
     // profiling
@@ -354,6 +360,7 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     TG_LAUNCH((tg_prep_sk<PR>), (n1 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH_CK();
+    if (L.T == 256) { const int rc = tg_lds_attr<PR, TgGeoSmall>(); if (rc != TG_OK) return rc; }     // (the backward GEMM may run on 128^2 tiles)
     return L.T == 256 ? tg_lds_attr<PR, TgGeoLarge>() : tg_lds_attr<PR, TgGeoSmall>();
 }
 
@@ -562,7 +569,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     m->cfg = *cfg; m->L = L;
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
-    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->comm = nullptr;
+    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->bwd_tuned = false; m->comm = nullptr;
     // M, Adam m, v (fp32) and X (fp32 or bf16) of this handle against the 256 MB MALL, with room left for the GEMM operands
     m->stream_once = (size_t)L.C * L.Vp * (12 + (cfg->precision == TG_PREC_BF16 ? 2 : 4)) > ((size_t)192 << 20);
     m->s_adam = nullptr; m->s_fwd = nullptr;
@@ -756,7 +763,7 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
 // backward GEMM (X, row-dot partials) over the cell tiles [ct0, ct1) on `stream`; `x_only`: no row dots (they are
 // taken by tg_adam_rowpass)
 template <class PR>
-static TgBwdArgs tg_bwd_args(tg_mapper* m, int ct0, int ct1, int* grid_out) {
+static TgBwdArgs tg_bwd_args(tg_mapper* m, int ct0, int ct1, int* grid_out, int tile = 0) {      // (ct0, ct1 in tiles of `tile` cells; 0 = L.T)
     const TgLayout& L = m->L;
     TgBwdArgs a;
     a.dG = m->ws + L.o_dG;
@@ -768,12 +775,12 @@ static TgBwdArgs tg_bwd_args(tg_mapper* m, int ct0, int ct1, int* grid_out) {
     a.dens_w = m->cfg.has_d_source ? m->fp(L.o_densw) : nullptr;
     a.part = m->fp(L.o_part);
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.nsteps = L.Kp / PR::BKE;
-    const int nct = ct1 - ct0;
+    const int nct = ct1 - ct0, nvt = tile ? L.Vr / tile : L.nvt;
     a.ct_offset = ct0;
     // XCD bands along the longer tile axis when it is long enough to feed 8 XCDs, otherwise a plain linear order
-    if (nct >= 16 && nct >= L.nvt) { a.map = TgTileMap{1, nct, L.nvt}; a.map_major_is_cells = 1; }
-    else if (L.nvt >= 16) { a.map = TgTileMap{1, L.nvt, nct}; a.map_major_is_cells = 0; }
-    else { a.map = TgTileMap{0, L.nvt, nct}; a.map_major_is_cells = 0; }
+    if (nct >= 16 && nct >= nvt) { a.map = TgTileMap{1, nct, nvt}; a.map_major_is_cells = 1; }
+    else if (nvt >= 16) { a.map = TgTileMap{1, nvt, nct}; a.map_major_is_cells = 0; }
+    else { a.map = TgTileMap{0, nvt, nct}; a.map_major_is_cells = 0; }
     a.lambda_r = m->cfg.lambda_r; a.lambda_l1 = m->cfg.lambda_l1; a.lambda_l2 = m->cfg.lambda_l2;
     *grid_out = tg_tilemap_grid(a.map);
     return a;
@@ -783,11 +790,13 @@ template <class PR>
 static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bool x_only = false) {
     const TgLayout& L = m->L;
     int grid;
-    const TgBwdArgs a = tg_bwd_args<PR>(m, ct0, ct1, &grid);
     // (the cached-access variant exists for the single-GPU X-only epilogue only: the row-dot variants serve spot shards and
     //  very long rows, i.e. big problems, and every GEMM instantiation costs seconds of compile time)
+    // ct0, ct1 count tiles of L.T cells; under the 256 layout the kernel may run on 128^2 tiles (L.bwd_T, see tg_tune_bwd)
+    const int f = L.T / L.bwd_T;
+    const TgBwdArgs a = tg_bwd_args<PR>(m, f * ct0, f * ct1, &grid, L.bwd_T);
 #define TG_BWD_GO(GE, F, R, S) TG_LAUNCH((tg_bwd_kernel<PR, GE, F, R, S>), grid, 1, GE::NT, GE::BWD_LDS_BYTES, stream, a)
-    if (L.T == 256) {
+    if (L.bwd_T == 256) {
         if (x_only) { if (m->stream_once) TG_BWD_GO(TgGeoLarge, false, false, true); else TG_BWD_GO(TgGeoLarge, false, false, false); }
         else if (L.full) TG_BWD_GO(TgGeoLarge, true, true, true);
         else TG_BWD_GO(TgGeoLarge, false, true, true);
@@ -799,10 +808,47 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
 #undef TG_BWD_GO
 }
 
+// Which tile geometry for the backward GEMM of THIS problem on THIS device: under the 256 layout both 256^2 (one workgroup per CU)
+// and 128^2 (two) are legal, and which one wins depends on how the tile count quantises into rounds of workgroups and on the
+// operand reuse in L2 (measured, profiles/r02/run10_tiles: 30k x 1k x 10k 256^2 by 4 %, 10k x 1k x 10k and 20k x 2k x 3k 128^2 by
+// 15 - 17 %).  Timed once per handle, on the first step, with the real operands in place (X-only epilogue: the result is bit-
+// identical for both geometries, every element is the same k-ordered sum).  TANGRAM_AMD_BWD_TILE=128|256 pins it (also for the
+// row-dot paths of spot shards, which are not timed: their partial sums depend on the tile width).
+template <class PR>
+static void tg_tune_bwd(tg_mapper* m, bool x_only) {
+    TgLayout& L = m->L;
+    if (m->bwd_tuned) return;
+    m->bwd_tuned = true;
+    if (L.T != 256 || L.bands > 1) return;
+    const char* pin = getenv("TANGRAM_AMD_BWD_TILE");
+    if (pin && *pin) { const int t = atoi(pin); if (t == 128 || t == 256) L.bwd_T = t; return; }
+#ifndef TG_SIM
+    if (!x_only || m->cfg.tile_size != 0) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
+    float best = 3.0e38f;
+    int best_T = 256;
+    for (int t = 256; t >= 128; t -= 128) {
+        L.bwd_T = t;
+        tg_launch_bwd<PR>(m, m->stream, 0, L.nct, true);                       // warm-up (code object, L2)
+        (void)hipEventRecord(e0, m->stream);
+        for (int r = 0; r < 2; ++r) tg_launch_bwd<PR>(m, m->stream, 0, L.nct, true);
+        (void)hipEventRecord(e1, m->stream);
+        float ms = 3.0e38f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best_T = 256; break; }
+        if (ms < best * (t == 128 ? 0.98f : 1.f)) { best = ms; best_T = t; }   // (128 has to win by 2 %: ties stay on 256)
+    }
+    L.bwd_T = best_T;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#else
+    (void)x_only;
+#endif
+}
+
 static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1) {
     const TgLayout& L = m->L;
     TgRowsumArgs r;
-    r.part = m->fp(L.o_part); r.nvt = L.nvt; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
+    r.part = m->fp(L.o_part); r.nvt = L.Vr / L.bwd_T; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
     r.c_begin = c0; r.c_end = c1;
     TG_LAUNCH(tg_rowsum_parts, (c1 - c0 + 255) / 256, 1, 256, 0, stream, r);
 }
@@ -844,6 +890,7 @@ static TgUpdateArgs tg_update_args(tg_mapper* m, float lr, bool finalize, int c0
 template <class PR>
 static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
+    tg_tune_bwd<PR>(m, false);
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);
     tg_prof_mark(m, "tg_bwd_kernel");
     tg_launch_rowsum(m, m->stream, 0, L.C);
@@ -908,6 +955,7 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     if (m->L.V <= TG_ROWPASS_MAX_V) {
         // a row of M and X fits the registers of one workgroup: the backward GEMM only stores X, the row dots are fused
         // into the update (tg_adam_rowpass), which also leaves the regulariser row sums for tg_hist_regs / the filter
+        tg_tune_bwd<PR>(m, true);
         tg_launch_bwd<PR>(m, m->stream, 0, m->L.nct, true);
         tg_prof_mark(m, "tg_bwd_kernel");
         if (tg_launch_failed()) return tg_launch_status();       // stop at the first failed launch, named
@@ -1271,6 +1319,7 @@ static int tg_one_step_sharded(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     if ((rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;                                    // (coefficients; dGhat operand image)
+    tg_tune_bwd<PR>(m, false);
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);                                                // X + row-dot partials of this rank's spots
     tg_prof_mark(m, "tg_bwd_kernel");
     tg_launch_rowsum(m, m->stream, 0, L.C);

@@ -65,6 +65,59 @@ def test_k1000_multi_tile_against_oracle_fp64(oracle_k1000, precision, tile):
     e.release()
 
 
+def test_backward_tile_choice_does_not_change_the_result(monkeypatch):
+    """Under the 256 layout the backward GEMM runs on 256^2 or 128^2 tiles, whichever tg_tune_bwd times faster on the first step
+    (TANGRAM_AMD_BWD_TILE pins it): every X element is the same k-ordered sum, so mapping and history are bit-identical; and a
+    1-rank spot shard (row-dot epilogue) on either geometry matches the fp64 oracle."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import make_sharded
+    from tangram_amd import _capi
+    from tests.local_comm import run_ranks
+    from oracle import tangram_oracle as orc
+    C, K, V, n = 6100, 48, 2900, 3
+    data = orc.make_synthetic(C, K, V, seed=33)
+    M0 = orc.reference_init_M(C, V, 3)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-4)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(n, 0.1)
+
+    def alone():
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam)
+        assert e.cfg.tile_size == 0
+        hist = e.new_history(n)
+        e.step(n, 0.1, hist)
+        out = hist.cpu().numpy(), e.result().cpu().numpy()
+        e.release()
+        return out
+
+    def check(hist, P, what):
+        for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss"), (_capi.H_KL, "kl_reg"), (_capi.H_ENTROPY, "entropy_reg")):
+            ref = np.array([float(x) for x in ho[k]])
+            err = np.abs(hist[:, col].astype(np.float64) - ref).max()
+            assert err <= 1e-5 * max(1.0, np.abs(ref).max()), (what, k, err)
+        assert np.abs(P - Po).max() <= 2e-4, what
+
+    monkeypatch.delenv("TANGRAM_AMD_BWD_TILE", raising=False)
+    h_auto, P_auto = alone()
+    check(h_auto, P_auto, "auto")
+    for pin in ("256", "128"):
+        monkeypatch.setenv("TANGRAM_AMD_BWD_TILE", pin)
+        h, P = alone()
+        np.testing.assert_array_equal(P, P_auto)
+        np.testing.assert_array_equal(h, h_auto)
+
+        def rank_fn(comm):
+            sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, comm=comm)
+            hh = sh.eng.new_history(n)
+            sh.run(n, 0.1, hh)
+            out = hh.cpu().numpy(), sh.result_full().cpu().numpy()
+            sh.release()
+            return out
+
+        (h1, P1), = run_ranks(1, rank_fn)
+        check(h1, P1, "1-rank shard, backward tiles " + pin)
+
+
 def _torch_reference(w, mode, M0, F0, steps):
     """The reference's op sequence in fp32 on the GPU (oracle/torch_port.py with device tensors): per-step history, the
     first-step gradient of M (and F)."""

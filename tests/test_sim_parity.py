@@ -84,6 +84,63 @@ def test_emulated_large_tile_geometry(sim, precision, K):
     assert np.abs(e.result().numpy() - Po).max() < tol["P"]
 
 
+@pytest.mark.parametrize("mode", ["mapper", "constrained"])
+def test_emulated_backward_on_small_tiles_under_the_256_layout(sim, mode, monkeypatch):
+    """TANGRAM_AMD_BWD_TILE=128: the backward GEMM of a 256-layout problem on 128^2 tiles (what tg_tune_bwd may pick on the GPU) --
+    alone (X-only epilogue) and as a 1-rank spot shard (row-dot epilogue, twice the partials per row); against the fp64 oracle,
+    and the X-only path bit-identical to the 256^2 run."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import make_sharded
+    from tests.local_comm import run_ranks
+    from oracle import tangram_oracle as orc
+    from tangram_amd import _capi
+    C, K, V = 610, 20, 270
+    data = orc.make_synthetic(C, K, V, seed=21)
+    n = 2
+    if mode == "constrained":
+        M0, F0 = orc.reference_init_MF_constrained(C, V, 5)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3, lambda_count=0.8, lambda_f_reg=1.2)
+        kw = dict(F0=F0, mode="constrained", target_count=100.0)
+        o = orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0, F0=F0, target_count=100.0, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(n, 0.1)
+    else:
+        M0 = orc.reference_init_M(C, V, 5)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3, lambda_l1=1e-4)
+        kw = {}
+        o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(n, 0.1)
+
+    def check(hist, P):
+        for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss"), (_capi.H_KL, "kl_reg"), (_capi.H_ENTROPY, "entropy_reg")):
+            ref = np.array([float(x) for x in ho[k]])
+            np.testing.assert_allclose(hist[:, col], ref, atol=1e-5 * max(1.0, np.abs(ref).max()), rtol=0, err_msg=k)
+        assert np.abs(P - Po).max() < 2e-4
+
+    def alone():
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=256, **kw)
+        hist = e.new_history(n)
+        e.step(n, 0.1, hist)
+        return hist.numpy().copy(), e.result().numpy().copy()
+
+    monkeypatch.setenv("TANGRAM_AMD_BWD_TILE", "256")
+    h256, P256 = alone()
+    monkeypatch.setenv("TANGRAM_AMD_BWD_TILE", "128")
+    h128, P128 = alone()
+    check(h128, P128)
+    np.testing.assert_array_equal(P128, P256)
+    np.testing.assert_array_equal(h128, h256)
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=256,
+                          comm=comm, **kw)
+        h = sh.eng.new_history(n)
+        sh.run(n, 0.1, h)
+        return h.numpy(), sh.result_full().numpy()
+
+    (h1, P1), = run_ranks(1, rank_fn)
+    check(h1, P1)
+
+
 @pytest.mark.parametrize("bands,tile", [(3, 128), (2, 256)])
 def test_emulated_cell_band_pipeline(sim, bands, tile):
     """The 3-stream cell-band schedule (backward | Adam | next forward) must give the sequential schedule's results."""
