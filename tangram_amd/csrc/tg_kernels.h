@@ -174,24 +174,36 @@ TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_by
 }
 
 // XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup b to XCD b % 8 (observed, used for speed
-// only: any mapping is correct).  Each XCD owns a contiguous band of the `major` tile axis and walks it in
-// 8 x 8 supertiles, so the workgroups resident on one XCD share 8 + 8 operand panels through that XCD's
-// private 4 MiB L2 instead of re-fetching them over the fabric.  Workgroups that fall off the grid exit.
+// only: any mapping is correct).  Each XCD owns a contiguous band of the `major` tile axis (n_major / 8 rows, the first
+// n_major % 8 bands one more) and walks it in supertiles of up to 8 x 8 tiles, down the major axis first, so the workgroups
+// resident on one XCD share 8 + 8 operand panels through that XCD's private 4 MiB L2 instead of re-fetching them over the
+// fabric.  The enumeration is DENSE: supertiles are clipped to the band, so the only workgroups without a tile are the last
+// n_minor of the XCDs with the shorter bands (round 1 padded every band to whole 8 x 8 supertiles: 41 % of the workgroups of a
+// 118 x 5 grid, 37 % of a 40 x 40 one, were launched -- 128 KB of LDS each -- only to exit; profiles/r02/run11_dense_map).
 struct TgTileMap { int mode, n_major, n_minor; };     // mode 0: linear (major = b / n_minor)
 TG_HD int tg_tilemap_grid(const TgTileMap& m) {
     if (m.mode == 0) return m.n_major * m.n_minor;
-    const int nb = (m.n_major + 7) / 8, nsM = (nb + 7) / 8, nsm = (m.n_minor + 7) / 8;
-    return 8 * nsM * nsm * 64;
+    return 8 * ((m.n_major + 7) / 8) * m.n_minor;
 }
 TG_HD bool tg_tilemap(const TgTileMap& m, int b, int& major, int& minor) {
     if (m.mode == 0) { major = b / m.n_minor; minor = b % m.n_minor; return true; }
-    const int nb = (m.n_major + 7) / 8, nsM = (nb + 7) / 8;
-    const int x = b & 7, j = b >> 3, s = j >> 6, w = j & 63;
-    const int sM = s % nsM, sm = s / nsM;
-    const int ml = sM * 8 + (w & 7);
-    major = x * nb + ml;
-    minor = sm * 8 + (w >> 3);
-    return ml < nb && major < m.n_major && minor < m.n_minor;
+    const int x = b & 7, j = b >> 3;
+    const int q = m.n_major >> 3, r = m.n_major & 7;
+    const int R = q + (x < r ? 1 : 0);                    // rows of this XCD's band
+    const int row0 = x * q + (x < r ? x : r);
+    if (j >= R * m.n_minor) { major = 0; minor = 0; return false; }
+    const int strip = R * 8;                              // tiles of a full 8-column strip of the band
+    int sm = j / strip;
+    const int nfull = m.n_minor >> 3;
+    if (sm > nfull) sm = nfull;
+    const int wc = (sm < nfull) ? 8 : (m.n_minor & 7);    // columns of this strip (the last one may be narrower)
+    const int rem = j - sm * strip;
+    int sM = rem / (8 * wc);
+    const int hr = (R - 8 * sM < 8) ? R - 8 * sM : 8;      // rows of this supertile
+    const int rem2 = rem - sM * 8 * wc;
+    major = row0 + 8 * sM + rem2 % hr;
+    minor = 8 * sm + rem2 / hr;
+    return true;
 }
 
 // ----------------------------------------------------------------------------------------------

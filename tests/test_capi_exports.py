@@ -55,7 +55,7 @@ def test_product_path_has_no_cpu_fallback():
         Mapper(np.ones((4, 3), np.float32), np.ones((5, 3), np.float32), device="cpu")
 
 
-@pytest.mark.parametrize("n_major,n_minor", [(235, 79), (79, 235), (16, 1), (17, 3), (64, 64), (1563, 391)])
+@pytest.mark.parametrize("n_major,n_minor", [(235, 79), (79, 235), (16, 1), (17, 3), (64, 64), (1563, 391), (118, 5), (40, 40), (3, 9), (118, 40)])
 def test_xcd_tile_map_is_a_bijection(n_major, n_minor):
     """Every tile of the backward grid is visited exactly once by the XCD-banded supertile order."""
     from tangram_amd import _build
@@ -70,11 +70,27 @@ def test_xcd_tile_map_is_a_bijection(n_major, n_minor):
                 assert (mj.value, mn.value) not in seen
                 seen.add((mj.value, mn.value))
         assert len(seen) == n_major * n_minor
-        if mode == 1:      # band property: a workgroup's XCD (b % 8) owns a contiguous band of the major axis
-            nb = (n_major + 7) // 8
+        if mode == 1:      # band property: a workgroup's XCD (b % 8) owns a contiguous band of the major axis; dense enumeration
+            q, r = divmod(n_major, 8)
+            assert grid == 8 * ((n_major + 7) // 8) * n_minor
             for b in range(0, grid, 97):
-                if lib.tg_debug_tilemap(1, n_major, n_minor, b, ctypes.byref(mj), ctypes.byref(mn)):
-                    assert mj.value // nb == b % 8
+                x = b % 8
+                row0, rows = x * q + min(x, r), q + (1 if x < r else 0)
+                ok = lib.tg_debug_tilemap(1, n_major, n_minor, b, ctypes.byref(mj), ctypes.byref(mn))
+                assert bool(ok) == ((b >> 3) < rows * n_minor)
+                if ok:
+                    assert row0 <= mj.value < row0 + rows
+            # the first workgroups of an XCD fill ONE supertile: <= 8 rows x <= 8 columns, down the major axis first
+            for x in (0, 7):
+                rows = q + (1 if x < r else 0)
+                n_first = min(rows, 8) * min(n_minor, 8)
+                local = []
+                for j in range(n_first):
+                    assert lib.tg_debug_tilemap(1, n_major, n_minor, 8 * j + x, ctypes.byref(mj), ctypes.byref(mn))
+                    local.append((mj.value, mn.value))
+                if local:
+                    assert len({a for a, _ in local}) == min(rows, 8) and len({c for _, c in local}) == min(n_minor, 8)
+                    assert local[1][0] == local[0][0] + 1 or rows == 1
 
 
 @pytest.mark.parametrize("nvt,nkt,nsplit", [(79, 8, 4), (1, 1, 1), (3, 2, 5), (10, 3, 1), (391, 16, 2)])
