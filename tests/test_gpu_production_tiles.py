@@ -65,6 +65,63 @@ def test_k1000_multi_tile_against_oracle_fp64(oracle_k1000, precision, tile):
     e.release()
 
 
+EDGE_SHAPES = [
+    # C, K, V, expected tile edge, expected wide forward (bf16x3)   -- boundaries of tg_make_layout's rules
+    (4096, 1, 448, 256, 0),        # smallest problem on the 256 layout; a single gene (+ the density column)
+    (4097, 511, 449, 256, 1),      # one past every multiple: 17 cell tiles, 2 spot tiles, 512 padded gene columns -> wide forward
+    (4100, 512, 1025, 256, 0),     # 513 columns pad to 768: not a multiple of 512 -> the 256^2 forward
+    (4095, 40, 3000, 128, 0),      # one cell short of the 256 layout
+    (5000, 30, 600, 128, 0),       # spots would pad 640 -> 768 (+20 %): stays on 128
+    (9000, 70, 257, 128, 0),       # V < 448
+]
+
+
+@pytest.mark.parametrize("mode", ["mapper", "constrained"])
+@pytest.mark.parametrize("C,K,V,tile,wide", EDGE_SHAPES)
+def test_layout_boundaries_against_oracle_fp64(C, K, V, tile, wide, mode):
+    """Ragged shapes at the boundaries of the geometry rules (layout 128 / 256, wide forward, dense tile map with bands of unequal
+    height, a single gene) against the fp64 oracle: 3 epochs of history, the mapping, the filter and the projection."""
+    import ctypes as ct
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    from oracle import tangram_oracle as orc
+    n = 3
+    data = orc.make_synthetic(C, K, V, seed=C + K + V)
+    if mode == "constrained":
+        M0, F0 = orc.reference_init_MF_constrained(C, V, 11)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.4, lambda_r=1e-4, lambda_count=0.9, lambda_f_reg=1.1)
+        kw = dict(F0=F0, mode="constrained", target_count=0.4 * V)
+        o = orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0, F0=F0, target_count=0.4 * V, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(n, 0.1)
+    else:
+        M0 = orc.reference_init_M(C, V, 11)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.4, lambda_l2=1e-7)
+        kw, Fo = {}, None
+        o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(n, 0.1)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, **kw)
+    geo = (ct.c_int * 8)()
+    assert e._lib.tg_debug_layout(ct.byref(e.cfg), geo) == 0
+    assert (geo[0], geo[5]) == (tile, wide)
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    h = hist.cpu().numpy().astype(np.float64)
+    for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss"), (_capi.H_VG, "vg_reg"), (_capi.H_KL, "kl_reg")):
+        ref = np.array([float(x) for x in ho[k]])
+        err = np.abs(h[:, col] - ref).max()
+        assert err <= 1e-5 * max(1.0, np.abs(ref).max()), (k, err)
+    if mode == "constrained":
+        P, F = e.result(with_filter=True)
+        assert np.abs(F.cpu().numpy() - Fo).max() <= 2e-5
+    else:
+        P = e.result()
+    assert np.abs(P.cpu().numpy() - Po).max() <= 2e-4
+    Gh = e.project().cpu().numpy()
+    want = (Po * Fo[:, None]).T @ data["S"].astype(np.float64) if mode == "constrained" else Po.T @ data["S"].astype(np.float64)
+    assert np.linalg.norm(Gh - want) / np.linalg.norm(want) <= 1e-4
+    e.release()
+
+
 def test_backward_tile_choice_does_not_change_the_result(monkeypatch):
     """Under the 256 layout the backward GEMM runs on 256^2 or 128^2 tiles, whichever tg_tune_bwd times faster on the first step
     (TANGRAM_AMD_BWD_TILE pins it): every X element is the same k-ordered sum, so mapping and history are bit-identical; and a

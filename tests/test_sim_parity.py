@@ -190,6 +190,67 @@ def test_emulated_degenerate_shapes(sim, shape):
     np.testing.assert_allclose(e.project().numpy(), Po.T @ S.astype(np.float64), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_emulated_random_configurations(sim, case):
+    """Seeded random draws of shape, mode, regularisers, priors and GEMM precision (ragged sizes around the 128-tile, 64-pitch and
+    32 / 64-step boundaries), 3 epochs each against the fp64 oracle: history columns, mapping, filter."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    from tangram_amd import _capi
+    rng = np.random.default_rng(1000 + case)
+    C = int(rng.choice([1, 7, 31, 33, 63, 65, 127, 129, 140]))
+    K = int(rng.choice([1, 2, 15, 31, 64, 127, 130]))
+    V = int(rng.choice([1, 3, 63, 64, 65, 128, 131, 200]))
+    precision = ["fp32", "bf16x3", "bf16x3", "bf16"][int(rng.integers(4))]
+    constrained = bool(rng.integers(2))
+    data = orc.make_synthetic(C, K, V, seed=50 + case)
+    n = 3
+    pick = lambda vals: float(rng.choice(vals))
+    lam = dict(lambda_g1=pick([1.0, 0.7]), lambda_d=pick([0.0, 1.0, 0.5]), lambda_g2=pick([0.0, 0.5]), lambda_r=pick([0.0, 1e-3]))
+    d = data["d"] if lam["lambda_d"] > 0 or constrained else None
+    if d is None:
+        lam["lambda_d"] = 0.0
+    if constrained:
+        lam["lambda_d"] = lam["lambda_d"] or 1.0
+        lam.update(lambda_count=pick([1.0, 0.3]), lambda_f_reg=pick([1.0, 2.0]))
+        tc = max(1.0, 0.5 * C)
+        M0, F0 = orc.reference_init_MF_constrained(C, V, case)
+        o = orc.OracleMapperConstrained(data["S"], data["G"], d, M0=M0, F0=F0, target_count=tc, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(n, 0.1)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=d, F0=F0, mode="constrained", device="cpu", precision=precision, lambdas=lam,
+                            target_count=tc)
+    else:
+        lam.update(lambda_l1=pick([0.0, 1e-4]), lambda_l2=pick([0.0, 1e-5]))
+        ds = None
+        if d is not None and rng.integers(2):
+            ds = rng.dirichlet(np.ones(C)).astype(np.float32)
+        M0 = orc.reference_init_M(C, V, case)
+        o = orc.OracleMapper(data["S"], data["G"], d=d, d_source=ds, M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(n, 0.1)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=d, d_source=ds, device="cpu", precision=precision, lambdas=lam)
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    h = hist.numpy().astype(np.float64)
+    tol = pc.TOL[precision]
+    cols = [(_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss")]
+    if lam["lambda_g2"] > 0:
+        cols.append((_capi.H_VG, "vg_reg"))
+    if lam["lambda_d"] > 0:
+        cols.append((_capi.H_KL, "kl_reg"))
+    if lam["lambda_r"] > 0:
+        cols.append((_capi.H_ENTROPY, "entropy_reg"))
+    for col, k in cols:
+        ref = np.array([float(x) for x in ho[k]])
+        err = np.abs(h[:, col] - ref).max()
+        assert err <= 3 * tol["loss"] * max(1.0, np.abs(ref).max()), (case, C, K, V, precision, constrained, k, err)
+    if constrained:
+        P, F = e.result(with_filter=True)
+        assert np.abs(F.numpy() - Fo).max() <= (2e-5 if precision != "bf16" else 5e-3)
+    else:
+        P = e.result()
+    assert np.abs(P.numpy() - Po).max() <= tol["P"], (case, C, K, V, precision)
+
+
 @pytest.mark.parametrize("precision,rtol", [("fp32", 2e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)])
 def test_emulated_project_genes_all_genes(sim, precision, rtol):
     """tg_mapper_project_genes: softmax(M)^T S_all over a gene set wider than the training genes (several blocks of
