@@ -221,6 +221,11 @@ int tg_mapper_validate(tg_mapper* m, float* out4_dev);
  * raw pointers to M / Adam m / Adam v inside `state` and the step counter.                          */
 int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, float** m2_dev, int32_t* pitch, int64_t* step);
 int tg_mapper_set_step(tg_mapper* m, int64_t step);   /* after restoring state: recompute softmax statistics */
+/* Constrained mode: the filter logits F and their two Adam moments, three rows of `pitch` floats (row 0 = F, mapping_optimizer.py:
+ * 486-493; rows 1, 2 = exp_avg, exp_avg_sq of torch.optim.Adam).  A checkpoint = these + tg_mapper_state; restore into a fresh
+ * handle, then tg_mapper_set_step.  The resumed run equals the uninterrupted one up to the rounding of the softmax normaliser
+ * (set_step rebuilds the per-row statistics that the update kernel otherwise carries from step to step).              */
+int tg_mapper_filter_state(tg_mapper* m, float** F_rows_dev, int32_t* pitch);
 
 /* Timing hooks for bench.py: while enabled, a HIP event is recorded on the handle's stream after every
  * kernel launch of tg_mapper_step (no synchronisation).  tg_mapper_profile_read synchronises the stream once,

@@ -88,6 +88,8 @@ def _declare(lib):
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
     lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
+    lib.tg_mapper_filter_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(ct.c_int32)]
+    lib.tg_mapper_filter_state.restype = i32
     lib.tg_mapper_validate.argtypes = [vp, vp]
     lib.tg_mapper_profile.argtypes = [vp, i32]
     lib.tg_mapper_profile_read.argtypes = [vp, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_float), ct.POINTER(i32), i32,
@@ -103,7 +105,8 @@ EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_creat
            "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_destroy",
            "tg_mapper_attach_comm", "tg_mapper_result",
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
-           "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step", "tg_mapper_profile",
+           "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step",
+           "tg_mapper_filter_state", "tg_mapper_profile",
            "tg_mapper_profile_read", "tg_mapper_validate"]
 
 

@@ -1523,6 +1523,14 @@ extern "C" int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, floa
     return TG_OK;
 }
 
+extern "C" int tg_mapper_filter_state(tg_mapper* m, float** F_rows_dev, int32_t* pitch) {
+    if (!m) return tg_fail(TG_ERR_INVALID, "null mapper");
+    if (m->cfg.mode != TG_MODE_CONSTRAINED) return tg_fail(TG_ERR_STATE, "only MapperConstrained has a filter");
+    if (F_rows_dev) *F_rows_dev = (float*)(m->st + m->L.s_F);
+    if (pitch) *pitch = m->L.Cp;
+    return TG_OK;
+}
+
 extern "C" int tg_mapper_set_step(tg_mapper* m, int64_t step) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (step < 0) return tg_fail(TG_ERR_INVALID, "step < 0");

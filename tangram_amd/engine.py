@@ -269,6 +269,13 @@ class HipMapperEngine:
             out.append(self.state[off:off + 4 * self.C * pitch.value].view(torch.float32).view(self.C, pitch.value))
         return out[0], out[1], out[2], int(step.value)
 
+    def filter_state(self):
+        """Constrained mode: [3, pitch] view of the filter logits F and their two Adam moments (columns >= C are padding)."""
+        pf, pitch = ct.c_void_p(), ct.c_int32()
+        self._call(self._lib.tg_mapper_filter_state, self._h, ct.byref(pf), ct.byref(pitch))
+        off = pf.value - self.state.data_ptr()
+        return self.state[off:off + 4 * 3 * pitch.value].view(torch.float32).view(3, pitch.value)
+
     def set_step(self, step):
         self._call(self._lib.tg_mapper_set_step, self._h, int(step))
 

@@ -139,6 +139,35 @@ def test_full_size_properties_cfg2():
     assert step == n + 1
 
 
+def test_checkpoint_resume_on_gpu():
+    """tg_mapper_state / tg_mapper_set_step at production tiles: logits, both Adam moments and the step counter copied into a fresh
+    handle continue the run (same trajectory up to the rounding of the rebuilt softmax normaliser)."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    C, K, V = 4500, 60, 1300
+    data = orc.make_synthetic(C, K, V, seed=12)
+    M0 = orc.reference_init_M(C, V, 2)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
+    mk = lambda M: HipMapperEngine(data["S"], data["G"], M, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam)
+    a = mk(M0)
+    ha = a.new_history(9)
+    a.step(9, 0.1, ha)
+    b = mk(M0)
+    b.step(4, 0.1, b.new_history(4))
+    Mb, m1b, m2b, step = b.logits()
+    c = mk(np.zeros_like(M0))
+    Mc, m1c, m2c, _ = c.logits()
+    Mc.copy_(Mb); m1c.copy_(m1b); m2c.copy_(m2b)
+    c.set_step(step)
+    hc = c.new_history(9)
+    c.step(5, 0.1, hc, 4)
+    np.testing.assert_allclose(hc.cpu().numpy()[4:, :5], ha.cpu().numpy()[4:, :5], rtol=5e-6, atol=1e-7)
+    assert float((c.result() - a.result()).abs().max()) <= 5e-7
+    assert c.logits()[3] == 9
+    for e in (a, b, c):
+        e.release()
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_pipelined_schedule_matches_sequential(precision):
     """3-stream cell-band pipeline (backward | Adam | next forward overlap) vs the one-stream schedule on real hardware:

@@ -190,6 +190,53 @@ def test_emulated_degenerate_shapes(sim, shape):
     np.testing.assert_allclose(e.project().numpy(), Po.T @ S.astype(np.float64), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["mapper", "constrained"])
+def test_emulated_checkpoint_resume(sim, mode):
+    """tg_mapper_state / tg_mapper_set_step: logits + both Adam moments + step counter copied into a fresh handle continue the
+    run: same trajectory up to the rounding of the softmax normaliser (set_step rebuilds the row statistics the kernels otherwise
+    carry between iterations with a different summation order: 1 ulp)."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    from oracle import tangram_oracle as orc
+    _cols_cf = [_capi.H_COUNT, _capi.H_FREG]
+    C, K, V = 90, 20, 70
+    data = orc.make_synthetic(C, K, V, seed=4)
+    M0 = orc.reference_init_M(C, V, 2)
+    if mode == "constrained":
+        M0, F0 = orc.reference_init_MF_constrained(C, V, 2)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3, lambda_count=0.7, lambda_f_reg=1.3)
+        kw = dict(mode="constrained", target_count=40.0)
+    else:
+        F0, kw = None, {}
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3, lambda_l2=1e-6)
+    mk = lambda M, F=F0: HipMapperEngine(data["S"], data["G"], M, d=data["d"], F0=F, device="cpu", precision="bf16x3", lambdas=lam, **kw)
+    a = mk(M0)
+    ha = a.new_history(7)
+    a.step(7, 0.1, ha)
+    b = mk(M0)
+    hb = b.new_history(7)
+    b.step(3, 0.1, hb, 0)
+    Mb, m1b, m2b, step = b.logits()
+    assert step == 3
+    c = mk(np.zeros_like(M0), None if F0 is None else np.ones_like(F0))      # a fresh handle with unrelated logits
+    Mc, m1c, m2c, _ = c.logits()
+    Mc.copy_(Mb); m1c.copy_(m1b); m2c.copy_(m2b)
+    if mode == "constrained":
+        c.filter_state().copy_(b.filter_state())
+    c.set_step(step)
+    hc = c.new_history(7)
+    c.step(4, 0.1, hc, 3)
+    np.testing.assert_allclose(hc.numpy()[3:, :5], ha.numpy()[3:, :5], rtol=5e-6, atol=1e-7)
+    np.testing.assert_allclose(c.result().numpy(), a.result().numpy(), rtol=0, atol=1e-6)
+    if mode == "constrained":
+        np.testing.assert_allclose(c.result(with_filter=True)[1].numpy(), a.result(with_filter=True)[1].numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(hc.numpy()[3:, _cols_cf], ha.numpy()[3:, _cols_cf], rtol=5e-6, atol=1e-7)
+    else:
+        with pytest.raises(Exception):
+            c.filter_state()
+    assert c.logits()[3] == 7
+
+
 @pytest.mark.parametrize("case", range(16))
 def test_emulated_random_configurations(sim, case):
     """Seeded random draws of shape, mode, regularisers, priors and GEMM precision (ragged sizes around the 128-tile, 64-pitch and
