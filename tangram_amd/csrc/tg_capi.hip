@@ -822,8 +822,16 @@ static void tg_tune_bwd(tg_mapper* m, bool x_only) {
     if (L.T != 256 || L.bands > 1) return;
     const char* pin = getenv("TANGRAM_AMD_BWD_TILE");
     if (pin && *pin) { const int t = atoi(pin); if (t == 128 || t == 256) L.bwd_T = t; return; }
+    if (m->cfg.tile_size != 0) return;
+    if (!x_only) {
+        // row-dot epilogue (spot shards, very long rows): a fixed rule, so that a shape always takes the same summation order.
+        // 128^2 tiles when the 256^2 grid is a few rounds of workgroups with a thin last one (1/8 spot shard of 30k x 1k x 10k:
+        // 590 tiles = 2.3 rounds, 242 -> 222 us; at 4.6 and 9.2 rounds 256^2 wins: profiles/r02/run10_tiles, run11)
+        const double rounds = (double)L.nct * (double)L.nvt / 256.0, frac = rounds - (double)(long)rounds;
+        if (rounds < 4.0 && frac > 0.0 && frac < 0.4) L.bwd_T = 128;
+        return;
+    }
 #ifndef TG_SIM
-    if (!x_only || m->cfg.tile_size != 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
     float best = 3.0e38f;
