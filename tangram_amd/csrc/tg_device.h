@@ -52,8 +52,6 @@ TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) {
 TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
     memcpy(lds_wave_base + 16 * hipsim::lane_id(), src, 16);
 }
-TG_DEV unsigned tg_l2_touch(const unsigned char*) { return 0u; }
-TG_DEV void tg_l2_touch_done(unsigned) {}
 #else
 // ------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
@@ -95,15 +93,6 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-// L2 prefetch: gfx950 has no vector prefetch instruction, so one dword of the cache line is loaded into a register nobody
-// reads.  The load is in flight until the next vmcnt(0) (the end-of-step barrier of the GEMM loops); tg_l2_touch_done keeps the
-// register reserved until then, so that the asynchronous write cannot land in a register reused for something else.
-TG_DEV unsigned tg_l2_touch(const unsigned char* line) {
-    unsigned r;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(line) : "memory");
-    return r;
-}
-TG_DEV void tg_l2_touch_done(unsigned r) { asm volatile("" ::"v"(r)); }
 #endif
 
 TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }

@@ -41,10 +41,6 @@ template <bool STREAM, class T> TG_DEV void tg_st_stream(const T& v, T* p) {
 #ifndef TG_FWD_STAGGER
 #define TG_FWD_STAGGER (-1)   // forward kernel A-operand staging schedule: 0 = block after the MFMAs, 1 / 2 = phase-shifted halves
 #endif                        // (waves 0-3 / 4-7 early); -1 = per precision (measured, see tg_fwd_kernel)
-#ifndef TG_L2_PREFETCH
-#define TG_L2_PREFETCH 0      // experiment, NEGATIVE (profiles/r02/run12_l2_prefetch): GEMM loops touch the operand lines of the step
-                              // after next (one dword per thread, tg_l2_touch): forward 1.31 -> 1.66 ms, backward 1.21 -> 1.36
-#endif
 #ifndef TG_YOUNG_PRIO
 #define TG_YOUNG_PRIO 0       // experiment: static s_setprio(1) for the second-dispatched half of the waves of a GEMM workgroup
 #endif
@@ -403,13 +399,10 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
         store_stage(lds);
         if (early && s_begin + 1 < s_end) load_stage(s_begin + 1);
         __syncthreads();
-        const unsigned char* pf_row = a.St + ((size_t)k0 + (t < GE::TN ? t : 0)) * bpitch;     // L2 prefetch of the S^T rows (tg_l2_touch)
         for (int s = s_begin; s < s_end; ++s) {
             u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s - s_begin + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < s_end;
-            unsigned pf = 0u;
-            if (TG_L2_PREFETCH && t < GE::TN && s + 2 < s_end) pf = tg_l2_touch(pf_row + (size_t)(s + 2) * 128);
             const int step_m = early ? ((s + 2) < s_end ? s + 2 : -1) : (more ? s + 1 : -1);    // M block to fetch during this step
             if (early && more) store_stage(nxt);    // (`nxt` was last read in step s-1: every wave has passed that barrier)
             if (PR::NP == 2) {                      // next step's global loads / LDS-DMA trickle in between the MFMA groups
@@ -422,7 +415,6 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
             }
             if (!early && more) store_stage(nxt);
             __syncthreads();
-            tg_l2_touch_done(pf);
         }
     }
 
@@ -842,15 +834,10 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
         tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, 0, lds, t, wave);
         tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, 0, lds + GE::A_CHUNKS, t, wave);
         __syncthreads();
-        // L2 prefetch: thread t owns one 128-byte operand row segment of a step (TM + TN = NT rows per stage)
-        static_assert(GE::TM + GE::TN == GE::NT, "one operand row per thread");
-        const unsigned char* pf_row = (t < GE::TM) ? a.dG + ((size_t)v0 + t) * pitch : a.Sk + ((size_t)c0 + (t - GE::TM)) * pitch;
         for (int s = 0; s < nsteps; ++s) {
             u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
             const bool more = (s + 1) < nsteps;     // DMA of the next step lands while the matrix cores run, issued a few
-            unsigned pf = 0u;
-            if (TG_L2_PREFETCH && s + 2 < nsteps) pf = tg_l2_touch(pf_row + (size_t)(s + 2) * 128);   // its DMA is issued during step s + 1
             tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [&](int i) {     // copies per MFMA group (see tg_tile_mma)
                 constexpr int NG_B = TgMmaShape<PR, GE>::NG, NSP = (NG_B * 3) / 4 > 0 ? (NG_B * 3) / 4 : 1, NIT = GE::LA + GE::LB;
                 if (!more) return;
@@ -862,7 +849,6 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
                 }
             });
             __syncthreads();                        // drains the DMA (vmcnt) and releases `cur` for the step after next
-            tg_l2_touch_done(pf);
         }
     }
 
