@@ -214,7 +214,9 @@ int tg_cluster_aggregate(const float* X_dev, int64_t ld, int32_t n_cols, const i
                          int32_t n_clusters, int32_t mean, float* out_dev, int64_t ld_out, void* hip_stream);
 
 /* Replaces Mapper._val_loss_fn (mapping_optimizer.py:311-356), evaluated with the CURRENT logits:
- * out4_dev = { gene score + voxel score, gene score, sparsity-weighted gene score, normalised map entropy }.   */
+ * out4_dev = { gene score + voxel score, gene score, sparsity-weighted gene score, normalised map entropy }.
+ * On a spot shard (attached communicator) the call is collective: the per-gene sums, the spot-cosine and entropy sums and the
+ * non-zero fractions are all-reduced, every rank receives the same four numbers over ALL spots.                 */
 int tg_mapper_validate(tg_mapper* m, float* out4_dev);
 
 /* Checkpoint access (the reference's adata_map resume is a stub, mapping_optimizer.py:151-153):

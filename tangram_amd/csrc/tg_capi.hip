@@ -1500,7 +1500,7 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (!out4_dev) return tg_fail(TG_ERR_INVALID, "out is NULL");
     const TgLayout& L = m->L;
-    if (L.Vtot != L.V) return tg_fail(TG_ERR_UNSUPPORTED, "validation metrics are not available on a spot shard");
+    if (L.Vtot != L.V && !m->comm) return tg_fail(TG_ERR_STATE, "a spot shard needs tg_mapper_attach_comm before it can validate");
     if (m->cfg.mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_INVALID, "MapperConstrained has no validation loss (mapping_optimizer.py:589)");
     int rc;
     switch (m->cfg.precision) {
@@ -1510,12 +1510,22 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     }
     if (rc) return rc;
     if ((rc = tg_launch_ghat_stats(m, true))) return rc;
+    if (m->comm && (rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;      // per-gene sums over all spots
     TG_LAUNCH(tg_row_entropy, L.C, 1, 256, 64, m->stream, (const float*)(m->st + L.s_M), (const float*)m->fp(L.o_rshift),
               (const float*)m->fp(L.o_rinvz), L.V, L.Vp, m->fp(L.o_rowent));
     TgValArgs a;
     a.genestat = m->fp(L.o_genestat); a.gnorm2 = m->fp(L.o_gnorm2); a.gfrac = m->fp(L.o_gfrac);
     a.voxstat = m->fp(L.o_voxstat); a.nky = (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS; a.vnorm2 = m->fp(L.o_vnorm2); a.rowent = m->fp(L.o_rowent);
     a.out = out4_dev; a.K = L.K; a.Kp = L.Kp; a.V = L.V; a.Vr = L.Vr; a.C = L.C;
+    a.V_total = L.Vtot; a.partial = 0; a.part = nullptr; a.gfrac_scale = (float)((double)L.V / (double)L.Vtot);
+    if (m->comm) {
+        // the sums over spots, per rank -> all-reduce -> every rank finishes with the same numbers.  Scratch: the gene coefficient
+        // buffer [2][Kp] (rewritten by the loss kernels of the next step); Kp >= 128, so 64 + Kp floats fit.
+        a.part = m->fp(L.o_coef); a.partial = 1;
+        TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);
+        if ((rc = tg_comm_all_reduce(m, a.part, (size_t)64 + L.Kp))) return rc;
+        a.partial = 0;
+    }
     TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);
     TG_LAUNCH_CK();
     return TG_OK;

@@ -1778,32 +1778,47 @@ struct TgValArgs {
     const float* voxstat; const float* vnorm2; const float* rowent;
     float* out;                                                          // [4]: gv + vg, gv, sparsity-weighted gv, entropy
     int K, Kp, V, Vr, C, nky;
+    // spot shards: the sums over spots are taken per rank (`partial` = 1: part[0] = sum of the spot cosines, part[1] = sum of the row
+    // entropies over this rank's spots, part[64 + k] = this rank's share of the non-zero fraction of gene k), all-reduced, and the
+    // final call (`partial` = 0, `part` non-null) reads them back instead of summing itself.  Alone: part = null.
+    int V_total, partial;
+    float* part;
+    float gfrac_scale;                                                   // V / V_total
 };
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_val_finalize(TgValArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;
     const int t = threadIdx.x;
+    float vs = 0.f, es = 0.f;
+    if (a.partial || !a.part) {
+        for (int v = t; v < a.V; v += 1024) {
+            float dot = 0.f, n2 = 0.f;
+            for (int y = 0; y < a.nky; ++y) { dot += a.voxstat[((size_t)y * 2 + 0) * a.Vr + v]; n2 += a.voxstat[((size_t)y * 2 + 1) * a.Vr + v]; }
+            const float na = tg_fmax(sqrtf(n2), TG_COS_EPS), nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
+            vs += dot / (na * nb);
+        }
+        vs = tg_block_sum_1024(vs, red);
+        for (int c = t; c < a.C; c += 1024) es += a.rowent[c];
+        es = tg_block_sum_1024(es, red);
+    } else { vs = a.part[0]; es = a.part[1]; }
+    if (a.partial) {
+        if (t < 64) a.part[t] = (t == 0) ? vs : ((t == 1) ? es : 0.f);
+        for (int k = t; k < a.Kp; k += 1024) a.part[64 + k] = (k < a.K) ? a.gfrac[k] * a.gfrac_scale : 0.f;
+        return;
+    }
+    const float* gfrac = a.part ? a.part + 64 : a.gfrac;
     float cs = 0.f, ws = 0.f, wn = 0.f;
     for (int k = t; k < a.K; k += 1024) {
         const float na = tg_fmax(sqrtf(a.genestat[a.Kp + k]), TG_COS_EPS), nb = tg_fmax(sqrtf(a.gnorm2[k]), TG_COS_EPS);
         const float c = a.genestat[k] / (na * nb);
         cs += c;
-        ws += c * a.gfrac[k];
-        wn += a.gfrac[k];
+        ws += c * gfrac[k];
+        wn += gfrac[k];
     }
     const float gv = tg_block_sum_1024(cs, red) / (float)a.K;
     const float wsum = tg_block_sum_1024(ws, red), wnorm = tg_block_sum_1024(wn, red);
-    float vs = 0.f;
-    for (int v = t; v < a.V; v += 1024) {
-        float dot = 0.f, n2 = 0.f;
-        for (int y = 0; y < a.nky; ++y) { dot += a.voxstat[((size_t)y * 2 + 0) * a.Vr + v]; n2 += a.voxstat[((size_t)y * 2 + 1) * a.Vr + v]; }
-        const float na = tg_fmax(sqrtf(n2), TG_COS_EPS), nb = tg_fmax(sqrtf(a.vnorm2[v]), TG_COS_EPS);
-        vs += dot / (na * nb);
-    }
-    const float vg = tg_block_sum_1024(vs, red) / (float)a.V;
-    float es = 0.f;
-    for (int c = t; c < a.C; c += 1024) es += a.rowent[c];
-    const float ent = tg_block_sum_1024(es, red) / ((float)a.C * logf((float)a.V));
+    const float vg = vs / (float)a.V_total;
+    const float ent = es / ((float)a.C * logf((float)a.V_total));
     if (t == 0) { a.out[0] = gv + vg; a.out[1] = gv; a.out[2] = wsum / wnorm; a.out[3] = ent; }
 }
 

@@ -187,8 +187,6 @@ class Mapper:
         if print_each:
             logging.info(f"Printing scores every {print_each} epochs.")
         eng = self._engine
-        if self._sharded is not None and val_each is not None:
-            raise NotImplementedError("val_each is not available on a spot-sharded (multi-GPU) run; pass distributed=False")
         run = self._sharded.run if self._sharded is not None else eng.step      # sharded: kernels + exchanges in one C call
         quiet = self._rank != 0                              # a sharded run prints its scores once, not once per rank
         hist = eng.new_history(max(int(num_epochs), 1))
@@ -207,7 +205,7 @@ class Mapper:
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
             if val_each is not None and (t - 1) % val_each == 0:
-                val_rows.append(eng.validate())              # reference :398-403: after optimizer.step() of epoch t-1
+                val_rows.append((self._sharded or eng).validate())   # reference :398-403: after optimizer.step() of epoch t-1
         P_dev = self._sharded.result_full() if self._sharded is not None else eng.result()
         output = P_dev.detach().cpu().numpy()                # reference :406-408
         history = self._history_dict(hist[:num_epochs])

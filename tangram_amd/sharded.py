@@ -152,6 +152,11 @@ class ShardedMapperEngine:
         hist = history_row.view(1, -1) if history_row is not None else None
         self.run(1, lr, hist, 0)
 
+    def validate(self):
+        """`_val_loss_fn` of the current mapping over ALL spots (collective: every rank calls it, every rank gets the same four
+        numbers): per-gene sums, spot-cosine sum, entropy sum and non-zero fractions are all-reduced inside tg_mapper_validate."""
+        return self._guard(self.eng.validate)
+
     def finalize_history(self, history):
         """Kept for callers of the earlier API: the rows written by `run` are already the global history."""
         return history

@@ -374,17 +374,20 @@ def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
         sh = make_sharded(data["S"], data["G"], M0, d=data["d"], d_source=ds, device=DEV, precision=precision, lambdas=lam, comm=comm)
         hist = sh.eng.new_history(n)
         sh.run(n, 0.1, hist)
-        return hist.cpu().numpy(), sh.result_full().cpu().numpy()          # (the rows `run` writes are the global history)
+        return hist.cpu().numpy(), sh.result_full().cpu().numpy(), sh.validate()    # (the rows `run` writes are the global history)
 
     res = run_ranks(world, rank_fn)
     e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], d_source=ds, device=DEV, precision=precision, lambdas=lam)
     h1 = e.new_history(n)
     e.step(n, 0.1, h1)
+    val1 = e.validate()
     h1, P1 = h1.cpu().numpy(), e.result().cpu().numpy()
     o = orc.OracleMapper(data["S"], data["G"], d=data["d"], d_source=ds, M0=M0, dtype=np.float64, **lam)
     Po, ho = o.train(n, 0.1)
     cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_L1, _capi.H_L2]
-    for hist, P in res:                                 # every rank holds the same reduced history and the full mapping
+    for hist, P, val in res:                            # every rank holds the same reduced history and the full mapping
+        np.testing.assert_allclose(val, val1, rtol=5e-6, atol=2e-7)          # _val_loss_fn over all spots, all-reduced in the library
+        assert val == res[0][2]
         np.testing.assert_allclose(hist[:, cols], h1[:, cols], atol=5e-6, rtol=2e-6)
         np.testing.assert_allclose(P, P1, atol=2e-6)
         np.testing.assert_allclose(hist[:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)

@@ -105,6 +105,23 @@ def test_two_shards_match_single_and_oracle(tmp_path):
     assert np.linalg.norm(z["Gc"] - ref) / np.linalg.norm(ref) < 1e-5
 
 
+def _val_each_run(device):
+    """`Mapper(...).train(val_each=2)` (the tuning path, mapping_parameter_tuning.py:110-129); under a process group the
+    validation metrics are sums over ALL spots (tg_mapper_validate all-reduces them)."""
+    import tangram_amd.mapping_optimizer as mo
+    from oracle import tangram_oracle as orc
+    C, K, V = 60, 16, 140
+    data = orc.make_synthetic(C, K, V, seed=8)
+    m = mo.Mapper(S=data["S"], G=data["G"], d=data["d"], lambda_d=1, lambda_g1=1, lambda_g2=0.5, device=device, random_state=7,
+                  gemm_precision="fp32")
+    P, hist = m.train(num_epochs=5, learning_rate=0.1, print_each=None, val_each=2)
+    out = {"val_P": P}
+    for k in hist:
+        if k.startswith("val_"):
+            out["valhist_" + k] = np.array([float(x) for x in hist[k]])
+    return out
+
+
 def _seam_worker(rank, world, port, sim_path, outdir):
     """The drop-in surface under a process group: the SAME call on every rank (what a user runs under torchrun)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -125,6 +142,7 @@ def _seam_worker(rank, world, port, sim_path, outdir):
             out[mode + "_loss"] = np.array([float(x) for x in ad_map.uns["training_history"]["total_loss"]])
             if mode == "constrained":
                 out["constrained_F"] = np.asarray(ad_map.obs["F_out"])
+        out.update(_val_each_run("cpu"))
         np.savez(os.path.join(outdir, f"seam_{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()
@@ -157,5 +175,14 @@ def test_map_cells_to_space_shards_over_the_process_group(tmp_path):
             np.testing.assert_array_equal(z0[mode + "_X"], z1[mode + "_X"])
             if mode == "constrained":
                 np.testing.assert_allclose(z0["constrained_F"], np.asarray(ad_map.obs["F_out"]), atol=2e-6)
+        single = _val_each_run("cpu")                 # val_each through the Mapper seam: sharded == single process
+        keys = [k for k in single if k.startswith("valhist_")]
+        assert len(keys) == 4 and all(len(single[k]) == 3 for k in keys)      # epochs 0, 2, 4
+        for z in (z0, z1):
+            np.testing.assert_allclose(z["val_P"], single["val_P"], atol=2e-6)
+            for k in keys:
+                np.testing.assert_allclose(z[k], single[k], rtol=5e-6, atol=1e-7, err_msg=k)
+        for k in keys:
+            np.testing.assert_array_equal(z0[k], z1[k])
     finally:
         _capi._install_library_for_tests(None)

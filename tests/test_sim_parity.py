@@ -365,16 +365,20 @@ def test_emulated_three_shards_in_threads(sim):
         sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam, comm=comm)
         h = sh.eng.new_history(3)
         sh.run(3, 0.1, h)
-        return sh.finalize_history(h).numpy(), sh.result_full().numpy()
+        return sh.finalize_history(h).numpy(), sh.result_full().numpy(), sh.validate()
 
     res = run_ranks(3, rank_fn)
     e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam)
     h1 = e.new_history(3)
     e.step(3, 0.1, h1)
+    val1 = e.validate()
     cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY]
-    for hist, P in res:
+    for hist, P, val in res:
         np.testing.assert_allclose(hist[:, cols], h1.numpy()[:, cols], atol=2e-6, rtol=1e-6)
         np.testing.assert_allclose(P, e.result().numpy(), atol=1e-6)
+        # _val_loss_fn over all spots (per-gene sums, spot cosines, entropy and non-zero fractions all-reduced in the library)
+        np.testing.assert_allclose(val, val1, rtol=2e-6, atol=1e-7)
+        assert val == res[0][2]                       # every rank holds the same four numbers
 
 
 def test_emulated_project_genes_from_csr(sim):
