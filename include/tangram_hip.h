@@ -151,8 +151,8 @@ void tg_mapper_destroy(tg_mapper* m);
  * into history_dev[(first_row + i) * TG_H_NTERMS ...] (device memory, may be NULL).
  * Asynchronous on the handle's stream, with one exception: the FIRST step of a handle whose layout uses 256-wide tiles and
  * whose tile_size is 0 times the backward GEMM on both tile sizes (a few launches, one hipEventSynchronize) and keeps the
- * faster; results do not depend on the choice.  TANGRAM_AMD_BWD_TILE=128|256 in the environment, or a non-zero
- * tg_config.tile_size, skip the timing (needed when the first step is to be captured into a HIP graph).   */
+ * faster; results do not depend on the choice.  Skipped (256^2 tiles kept) while the stream is being captured into a HIP
+ * graph; TANGRAM_AMD_BWD_TILE=128|256 in the environment or a non-zero tg_config.tile_size pin the choice without timing.  */
 int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row);
 
 /* Spot-sharded multi-GPU run: attach a communicator to a handle created with n_spots < n_spots_total (collective; performs the

@@ -832,6 +832,8 @@ static void tg_tune_bwd(tg_mapper* m, bool x_only) {
         return;
     }
 #ifndef TG_SIM
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;             // (a stream under graph capture must not be synchronised:
+    if (hipStreamIsCapturing(m->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;   //  stay on 256^2)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
     float best = 3.0e38f;
