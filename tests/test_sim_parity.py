@@ -348,6 +348,32 @@ def test_emulated_project_genes_constrained_filter(sim):
     np.testing.assert_allclose(e.project_genes(S_all, unfiltered=False).numpy(), P.T @ (S_all * F[:, None]), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("K", [22, 23])
+def test_emulated_spatial_terms_with_ragged_gene_counts(sim, K):
+    """All CSR spatial terms at gene counts that are not multiples of 4 (tg_spmm handles 4 genes per thread: the last, partial
+    quad is guarded per element) against the fp64 oracle."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    from tangram_amd import _capi
+    C, V = 50, 64
+    data = orc.make_synthetic(C, K, V, seed=K, n_types=3)
+    M0 = orc.reference_init_M(C, V, 9)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17,
+               lambda_getis_ord=0.3, lambda_moran=0.4, lambda_geary=0.2)
+    kw = dict(voxel_weights=orc.grid_graph(V, standardized=True, self_inclusion=True),
+              neighborhood_filter=orc.grid_graph(V, standardized=False, self_inclusion=False), ct_encode=data["ct_encode"],
+              spatial_weights=orc.grid_graph(V, standardized=True, self_inclusion=False))
+    n = 3
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam, **kw)
+    Po, ho = o.train(n, 0.1)
+    for prec in ("fp32", "bf16x3"):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision=prec, lambdas=lam, **kw)
+        hist = e.new_history(n)
+        e.step(n, 0.1, hist)
+        np.testing.assert_allclose(hist[:, _capi.H_TOTAL].numpy(), np.array(ho["total_loss"], dtype=np.float64), atol=2e-5, rtol=2e-5)
+        np.testing.assert_allclose(e.result().numpy(), Po, atol=5e-5)
+
+
 def test_emulated_three_shards_in_threads(sim):
     """tangram_amd.sharded with three spot shards as threads of this process (tests/local_comm.py; the gloo test in
     test_sharded_gloo.py covers real process groups): same history and mapping as the unsharded engine."""
