@@ -129,3 +129,30 @@ def test_launch_geometry_of_the_baseline_shapes():
     assert geo(30000, 1000, 1250, 2, v_total=10000, ranks=8)[:3] == [256, 118, 5]
     assert geo(30000, 700, 10000, 2)[5] == 0             # 701 gene columns pad to 768: not a multiple of 512
     assert geo(2000, 100, 500, 2)[0] == 128
+
+
+def test_sizes_of_the_large_configurations_do_not_overflow():
+    """tg_query_sizes on the host for BASELINE config 4 (200k x 2k x 50k, bf16: M + Adam moments = 120 GB on one GPU), its 1/8
+    spot shard, and a problem far beyond any GPU: 64-bit byte counts, consistent with the documented layout."""
+    from tangram_amd import _build, _capi
+    lib = _capi._declare(ctypes.CDLL(_build.build()))
+
+    def sizes(C, K, V, prec, v_total=0, ranks=0):
+        cfg = _capi.TgConfig()
+        cfg.abi_version = _capi.TG_ABI_VERSION
+        cfg.n_cells, cfg.n_genes, cfg.n_spots, cfg.n_spots_total, cfg.n_ranks = C, K, V, v_total, ranks
+        cfg.lambda_g1, cfg.has_density, cfg.lambda_d, cfg.precision = 1.0, 1, 1.0, prec
+        sz = _capi.TgSizes()
+        assert lib.tg_query_sizes(ctypes.byref(cfg), ctypes.byref(sz)) == 0, lib.tg_last_error()
+        return sz
+
+    s4 = sizes(200000, 2000, 50000, 1)
+    pitch = s4.m_pitch
+    assert pitch >= 50000 and pitch % 64 == 0
+    assert s4.state_bytes >= 3 * 200000 * pitch * 4 and s4.state_bytes < 3 * 200000 * pitch * 4 + (1 << 26)     # M, m, v (+ nothing big)
+    assert 200000 * pitch * 2 <= s4.workspace_bytes < 60 * (1 << 30)                 # bf16 X (20 GB) + operands + partials
+    assert s4.state_bytes + s4.workspace_bytes < 288 * (1 << 30)                     # fits one MI355X
+    s8 = sizes(200000, 2000, 6250, 1, v_total=50000, ranks=8)
+    assert s8.state_bytes < s4.state_bytes // 7 and s8.state_bytes >= 3 * 200000 * 6250 * 4
+    huge = sizes(2_000_000, 4000, 1_000_000, 2)
+    assert huge.state_bytes >= 3 * 2_000_000 * 1_000_000 * 4                          # 24 TB: counted, not allocated
