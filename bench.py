@@ -352,7 +352,9 @@ def main():
             "dtype": DTYPE_NAME[precision], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {C} cells x {K} genes x {V} spots, {wl_desc}; planted-mapping synthetic "
                                    f"counts, Adam lr=0.1", "gemm_precision": precision,
-                       "parallelism": "single GPU" if world == 1 else f"spots sharded over {world} GPUs, 3 small RCCL exchanges/step"},
+                       "parallelism": "single GPU" if world == 1 else
+                       f"spots sharded over {world} ranks, 3 small exchanges/step issued by the library ({getattr(owner, 'transport', '?')}: "
+                       f"{'RCCL on the compute stream' if getattr(owner, 'transport', '') == 'rccl' else backend + ' through callbacks'})"},
             "cell_spot_gene_per_s": its * C * K * V,
             "last_main_loss": main_loss,
             "roofline": roof,
