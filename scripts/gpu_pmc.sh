@@ -1,13 +1,12 @@
 #!/bin/bash
 # PMC counter passes (one rocprofv3 run per counter group, --pmc only: no trace domains) for bench.py.
-# usage: gpu_pmc.sh tag precision [traffic]      ("traffic": only the groups profiles/pmc_traffic.json is built from)
-TAG=${1:-pmc}; P=${2:-bf16}; MODE=${3:-all}
+# usage: gpu_pmc.sh tag precision [traffic|all] [keep]   ("traffic": only the groups profiles/pmc_traffic.json is built from)
+TAG=${1:-pmc}; P=${2:-bf16x3}; MODE=${3:-all}; KEEP=${4:-}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
-rm -rf $R/gpurun_out/*; mkdir -p $O
+[ -z "$KEEP" ] && rm -rf $R/gpurun_out/*
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp PYTHONUNBUFFERED=1
-rocprofv3 -L > $O/counters_list.txt 2>&1
-grep -oE "^\s*(Name|name)\s*:\s*\S+" $O/counters_list.txt | awk '{print $NF}' | sort -u > $O/counter_names.txt; wc -l $O/counter_names.txt
 i=0
 while read -r GROUP; do
   i=$((i+1))
@@ -22,8 +21,8 @@ TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 FETCH_SIZE
 WRITE_SIZE
 GRBM_GUI_ACTIVE GRBM_COUNT
-TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
-TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum
+SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES SQ_CYCLES
+TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 GROUPS
 cd $R
 python - $O <<'PY'
@@ -44,7 +43,7 @@ for f in sorted(glob.glob(O+"/g*/**/*counter_collection.csv",recursive=True)):
             for c,v in agg[k].items():
                 line="%-44s %-28s avg_per_dispatch=%.6g n=%d"%(k,c,v/cnt[(k,c)],cnt[(k,c)])
                 o.write(line+"\n")
-                if "bwd" in k or "fwd" in k: print(line)
+                if "bwd" in k or "fwd" in k or "rowpass" in k: print(line)
     os.remove(f)
 PY
 find $O -size +512k -delete; du -sh $R/gpurun_out; tail -3 $O/g1.log

@@ -11,7 +11,7 @@ import ctypes as ct
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TANGRAM_AMD_LIB") or os.path.join(_HERE, "csrc", "libtangram_hip.so")   # env: kernel A/B experiments
+LIB_PATH = os.path.join(_HERE, "csrc", "libtangram_hip.so")      # the in-tree build, nothing else (experiments: scripts/with_lib.py)
 
 TG_ABI_VERSION = 2
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1

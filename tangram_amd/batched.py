@@ -9,8 +9,9 @@ Clusters-mode problems are tiny (18 x 250 x 9852) and launch-bound on a 256-CU G
 `MapperBatch` / `train_many` advance B mappings of one shape in ONE launch per kernel: the C library's `tg_batch` puts the
 per-mapping kernel arguments into device arrays and adds a batch index to the grid of every kernel of the iteration
 (blockIdx.z = mapping).  Results are the bits of training the same mappings one by one: nothing is shared between them.
-Mappings that cannot be batched (different shapes, MapperConstrained, spatial terms, `val_each`) fall back to one HIP stream
-and host thread per mapping (the C ABI releases the GIL; different handles may be driven from different threads).
+Mappings that cannot be batched (a shape of their own, MapperConstrained, spatial terms, more than 16 384 spots, `val_each`, or
+a group the C library refuses) are trained by one host thread per mapping (the C ABI releases the GIL; different handles may be
+driven from different threads); `batched=False` additionally gives every mapping a HIP stream of its own.
 """
 from __future__ import annotations
 
@@ -62,15 +63,24 @@ class MapperBatch:
             pass
 
 
+ROWPASS_MAX_SPOTS = 16384          # TG_ROWPASS_MAX_V (tg_capi.hip): rows the single-kernel update holds in registers
+EMIT_MAX_GENE_COLS = 6128          # (2 Kp + 32) floats of dynamic LDS <= 48 KB in tg_dghat_emit<SELF>
+
+
 def _batch_key(m):
-    """Mappings with equal keys can share a tg_batch (the C library re-checks)."""
+    """Mappings with equal keys can share a tg_batch: the limits of tg_batch_create (tg_capi.hip) are applied here, so that a
+    group the C library would refuse is never formed (the C library re-checks; a refusal falls back to the stream path)."""
     e = getattr(m, "_engine", None)
     if type(m).__name__ != "Mapper" or e is None or getattr(m, "_sharded", None) is not None:
         return None
     c = e.cfg
     if c.lambda_neighborhood_g1 or c.lambda_ct_islands or c.lambda_getis_ord or c.lambda_moran or c.lambda_geary:
         return None
-    return (e.C, e.K, e.V, e.precision, bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device))
+    if e.V > ROWPASS_MAX_SPOTS or e.K + 1 + 256 > EMIT_MAX_GENE_COLS or c.pipeline_bands > 1:
+        return None
+    stream = e._torch_stream.cuda_stream if e._torch_stream is not None else 0
+    return (e.C, e.K, e.V, e.precision, bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device), stream,
+            c.beta1, c.beta2, c.tile_size, c.fwd_splits)
 
 
 def _train_batched(mappers, num_epochs, learning_rate):
@@ -91,9 +101,10 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
     builders: callables, each returning a `Mapper` / `MapperConstrained`.  They are called one after the other on the
               calling thread (the reference's initialisation draws from the global NumPy RNG, `np.random.seed(random_state)`,
               which must not be interleaved).
-    batched:  "auto" (default): mappings that can share a `tg_batch` (Mapper, one shape, no spatial terms, no `val_each`)
-              advance in ONE launch per kernel; the others are trained one after the other.  False: one HIP stream + host
-              thread per mapping (`max_concurrent` at a time) for everything.
+    batched:  "auto" (default): mappings that can share a `tg_batch` (Mapper, one shape, no spatial terms, <= 16 384 spots, no
+              `val_each`) advance in ONE launch per kernel; the others -- and any group the C library refuses -- get a host
+              thread each, their kernels sharing the common creation stream.  False: every mapper is created on a HIP stream
+              of its own and trained by its own host thread (`max_concurrent` at a time): kernels of different mappings overlap.
     Returns the list of `mapper.train(...)` results (in the order of `builders`) and the mappers themselves."""
     device = torch.device(device)
     builders = list(builders)
@@ -106,21 +117,46 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
             groups = {}
             for i, m in enumerate(mappers):
                 groups.setdefault(_batch_key(m) or ("single", i), []).append(i)
+            rest = []
             for key, idx in groups.items():
                 if key[0] != "single" and len(idx) > 1:
-                    for i, r in zip(idx, _train_batched([mappers[i] for i in idx], num_epochs, learning_rate)):
-                        results[i] = r
-                else:
-                    for i in idx:
-                        results[i] = mappers[i].train(num_epochs=num_epochs, learning_rate=learning_rate, print_each=None, **train_kwargs)
+                    try:
+                        for i, r in zip(idx, _train_batched([mappers[i] for i in idx], num_epochs, learning_rate)):
+                            results[i] = r
+                        continue
+                    except (RuntimeError, ValueError) as e:             # refused by tg_batch_create: nothing has been stepped yet
+                        if any(mappers[i]._engine.logits()[3] != 0 for i in idx):
+                            raise
+                        import logging
+                        logging.info("tangram_amd: %d mappings not batchable (%s); training them on streams", len(idx), e)
+                rest += idx
+        _train_on_streams(sorted(rest), mappers, results, device, num_epochs, learning_rate, max_concurrent, train_kwargs)
         return results, mappers
-    streams = [None] * n
-    with torch.cuda.device(device):
+    streams = {}
+    with (torch.cuda.device(device) if device.type == "cuda" else _null()):
         for i in range(n):
-            streams[i] = torch.cuda.Stream(device=device)
-            with torch.cuda.stream(streams[i]):
+            if device.type == "cuda":                           # the library binds a handle to the stream it is created on
+                streams[i] = torch.cuda.Stream(device=device)
+                with torch.cuda.stream(streams[i]):
+                    mappers[i] = builders[i]()
+                streams[i].synchronize()
+            else:
                 mappers[i] = builders[i]()
-            streams[i].synchronize()
+    _train_on_streams(list(range(n)), mappers, results, device, num_epochs, learning_rate, max_concurrent, train_kwargs, streams)
+    return results, mappers
+
+
+def _train_on_streams(idx, mappers, results, device, num_epochs, learning_rate, max_concurrent, train_kwargs, streams=None):
+    """One host thread per mapping, `max_concurrent` at a time, each on the HIP stream its mapper was created on (`streams`;
+    kernels of different mappings then overlap on the GPU).  Without `streams` (mappers built on one common stream, the
+    left-overs of the batched path) the threads only overlap the host side: a handle's kernels run on its creation stream."""
+    if not idx:
+        return
+    if device.type != "cuda":                                   # (emulated build of the CPU test-suite: no streams)
+        for i in idx:
+            results[i] = mappers[i].train(num_epochs=num_epochs, learning_rate=learning_rate, print_each=None, **train_kwargs)
+        return
+    streams = streams or {i: torch.cuda.Stream(device=device) for i in idx}
 
     def work(i):
         with torch.cuda.device(device), torch.cuda.stream(streams[i]):
@@ -128,9 +164,8 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
         streams[i].synchronize()
 
     with ThreadPoolExecutor(max_workers=max(1, int(max_concurrent))) as pool:
-        for f in [pool.submit(work, i) for i in range(n)]:
+        for f in [pool.submit(work, i) for i in idx]:
             f.result()
-    return results, mappers
 
 
 class _null:

@@ -41,12 +41,6 @@ template <bool STREAM, class T> TG_DEV void tg_st_stream(const T& v, T* p) {
 #ifndef TG_FWD_STAGGER
 #define TG_FWD_STAGGER (-1)   // forward kernel A-operand staging schedule: 0 = block after the MFMAs, 1 / 2 = phase-shifted halves
 #endif                        // (waves 0-3 / 4-7 early); -1 = per precision (measured, see tg_fwd_kernel)
-#ifndef TG_YOUNG_PRIO
-#define TG_YOUNG_PRIO 0       // experiment: static s_setprio(1) for the second-dispatched half of the waves of a GEMM workgroup
-#endif
-#ifndef TG_ABL_BWD
-#define TG_ABL_BWD 0          // ablation builds only (never shipped): 1 = backward GEMM without its global X stores, 2 = without epilogue
-#endif
 #define TG_NEG_BIG (-3.0e38f)
 #define TG_COS_EPS 1e-8f
 
@@ -247,9 +241,6 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
-#if TG_YOUNG_PRIO && !defined(TG_SIM)
-    if (TG_YOUNG_PRIO == 1 ? (wave >= GE::NT / 128) : (wave < GE::NT / 128)) __builtin_amdgcn_s_setprio(TG_YOUNG_PRIO >= 3 ? 3 : 1);
-#endif
     int vt, kt, split;
     const bool band = a.band_step_end > 0;
     if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, band ? 1 : a.nsplit, vt, kt, split)) return;
@@ -286,9 +277,6 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     const size_t bpitch = (size_t)a.nsteps * 128;
 
     auto load_m = [&](int step, int j) {                       // one float4 row of the M micro-block of `step`
-#if defined(TG_ABL_FWD) && TG_ABL_FWD >= 2
-        return;
-#endif
         if (!stager) return;
         const int c = step * PR::BKE + kc * PR::CH + half * RS + j;
         const int cc = c < a.C ? c : a.C - 1;
@@ -365,16 +353,6 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     };
     auto store_stage = [&](u32x4* st) {
         if (!stager) return;
-#if defined(TG_ABL_FWD) && TG_ABL_FWD >= 1      // experiment (wrong results): the forward without the arithmetic of its softmax staging
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * quad + i;
-            if constexpr (PR::NP == 2) {
-                ((u32x2*)(st + row * 8 + tg_swz(row, kc)))[half] = u32x2{0x38003800u, 0x38003800u};
-                ((u32x2*)(st + row * 8 + tg_swz(row, 4 + kc)))[half] = u32x2{0u, 0u};
-            } else st[row * 8 + tg_swz(row, slot)] = u32x4{0x38003800u, 0x38003800u, 0x38003800u, 0x38003800u};
-        }
-        return;
-#endif
         if (PR::NP == 2 && full_tile) store_stage_impl(st, std::false_type());     // (the second copy only pays off for bf16x3)
         else store_stage_impl(st, std::true_type());
     };
@@ -814,9 +792,6 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
-#if TG_YOUNG_PRIO && !defined(TG_SIM)
-    if (wave >= GE::NT / 128) __builtin_amdgcn_s_setprio(1);
-#endif
     int t_major, t_minor;
     if (!tg_tilemap(a.map, blockIdx.x, t_major, t_minor)) return;
     const int vt = a.map_major_is_cells ? t_minor : t_major, ct = a.ct_offset + (a.map_major_is_cells ? t_major : t_minor);
@@ -862,13 +837,6 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
     //                    (+ the entropy / L1 / L2 / filter row sums when FULL), reduced over the RC lanes of the row.  The M
     //                    segments of a whole pass are requested before the staging barrier (NIT loads in flight per lane);
     //                    the per-cell constants of the tile wait in the 4 KB of LDS behind the staging area.
-#if TG_ABL_BWD == 2 && !defined(TG_SIM)
-#pragma unroll
-    for (int i = 0; i < GE::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < GE::FN; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-#endif
     constexpr int RC = GE::TM / 4;                                        // 16-byte columns of a staged row (one cell, TM spots)
     constexpr int CPP = (GE::LDS_BYTES / (GE::TM * 4) < GE::TN) ? GE::LDS_BYTES / (GE::TM * 4) : GE::TN;   // cells per pass
     constexpr int NPASS = GE::TN / CPP, FPP = GE::FN / NPASS;             // passes, cell fragments per wave and pass
@@ -919,12 +887,7 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
             const int cl = cell_of(pass, row), c = c0 + cl;
             const bool ok = c < a.C && v < a.Vp;
             const f32x4 x = stg[row * RC + (j ^ (row & 15))];
-#if TG_ABL_BWD == 1 && !defined(TG_SIM)
-            asm volatile("" ::"v"(x));
-            if (false) {
-#else
             if (ok) {
-#endif
                 if constexpr (PR::X16)
                     tg_st_stream<STREAM>(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
                 else

@@ -17,11 +17,16 @@ matrix-core products), "fp32" (exact fp32 MFMA), "bf16"}; `distributed` / `group
     torchrun --nproc-per-node 8 script.py        # one process per GPU, torch.distributed.init_process_group("nccl")
     ad_map = tg.map_cells_to_space(adata_sc, adata_sp, device=f"cuda:{LOCAL_RANK}", ...)    # same call on every rank
 
-With a process group of more than one rank initialised, `Mapper` / `MapperConstrained` shard the SPOTS over the ranks
-(tangram_amd/sharded.py: each rank trains its block of columns of M, three small RCCL exchanges per iteration) and every
-rank returns the full mapping matrix and the same training history.  `distributed=False` keeps a mapper on its own GPU,
-`distributed=True` insists on sharding.  The initial logits are drawn exactly like the reference does on every rank (same
-seed, same full C x V draw) and then sliced, so a sharded run follows the single-GPU trajectory up to summation order.
+    ad_map = tg.map_cells_to_space(adata_sc, adata_sp, device=f"cuda:{LOCAL_RANK}", distributed=True, ...)
+
+Sharding is OPT-IN (`distributed=True`, optionally `group=`): a script may use its process group for independent per-rank work
+(folds, seeds, tuning trials), so an initialised group alone never makes a mapper collective.  With `distributed=True` the
+SPOTS are sharded over the ranks of the group (tangram_amd/sharded.py: each rank trains its block of columns of M, three small
+RCCL exchanges per iteration); the ranks first check that they were handed the same problem (shape, mode, terms), and every rank
+returns the full mapping matrix and the same training history.  The initial logits are drawn exactly like the reference does on
+every rank (same seed, same full C x V draw) and then sliced, so a sharded run follows the single-GPU trajectory up to summation
+order; an UNSEEDED sharded run (`random_state` None or 0) takes its seed from rank 0, so that all ranks still draw the same
+logits and filter.
 """
 from __future__ import annotations
 
@@ -56,23 +61,51 @@ def _to_numpy_f32(x):
 
 
 def _shard_context(distributed, group, blockers):
-    """(sharded?, world, rank): shard over the process group iff asked to, or -- `distributed=None` -- whenever
-    torch.distributed is initialised with more than one rank and nothing in `blockers` (spatial terms) forbids it."""
+    """(sharded?, world, rank).  Sharding is opt-in: `distributed=True` shards the spots over the process group (which must
+    be initialised); None / False keep the mapper on its own GPU even when a process group exists (the caller may be using
+    it for independent per-rank work)."""
     import torch.distributed as dist
     live = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if live else 1
     rank = dist.get_rank(group) if live else 0
-    if distributed is False or (distributed is None and world <= 1):
+    if not distributed:
         return False, world, rank
-    if distributed and not live:
+    if not live:
         raise RuntimeError("distributed=True needs an initialised torch.distributed process group (one rank per GPU)")
-    if blockers:
-        if distributed:
-            raise NotImplementedError("spot sharding is not available with " + ", ".join(blockers) +
-                                      " (the spatial terms need the whole spot graph on one GPU)")
-        logging.warning("tangram_amd: %s -> every rank trains the whole problem on its own GPU (no spot sharding)", ", ".join(blockers))
+    if world <= 1:
         return False, world, rank
+    if blockers:
+        raise NotImplementedError("spot sharding is not available with " + ", ".join(blockers) +
+                                  " (the spatial terms need the whole spot graph on one GPU)")
     return True, world, rank
+
+
+def _check_same_problem(group, device, signature):
+    """Every rank of a sharded mapper must have been handed the same problem: compare a small integer signature (shape, mode,
+    active terms) across the group before any state is built; a mismatch raises on EVERY rank instead of hanging later."""
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    dev = device if backend == "nccl" else torch.device("cpu")
+    mine = torch.tensor([int(x) for x in signature], dtype=torch.int64, device=dev)
+    world = dist.get_world_size(group)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    for r, other in enumerate(every):
+        if not torch.equal(other.cpu(), mine.cpu()):
+            raise ValueError(f"distributed=True: rank {r} was given a different problem than rank {dist.get_rank(group)} "
+                             f"({other.tolist()} vs {mine.tolist()}: cells, genes, spots, mode, terms); every rank must make the "
+                             "same call")
+
+
+def _shared_seed(group, device):
+    """An unseeded sharded run: rank 0 draws a seed from its global NumPy RNG (advancing it like any other draw), all ranks
+    use it -- otherwise every rank would slice a DIFFERENT logits / filter draw."""
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    dev = device if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(np.random.randint(1, 2**31 - 1))], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.item())
 
 
 def _print_terms(names_vals):
@@ -112,7 +145,7 @@ class Mapper:
         *,
         gemm_precision="bf16x3",
         M_init=None,
-        distributed=None,
+        distributed=False,
         group=None,
     ):
         if adata_map is not None:
@@ -142,10 +175,6 @@ class Mapper:
         d = _to_numpy_f32(d)
         d_source = _to_numpy_f32(d_source)
         # the reference ignores lambda_d when d is None (:212-221) and uses d_source only together with d (:214)
-        if M_init is None:
-            if self.random_state:                            # reference :148-150 (seed 0 / None => unseeded)
-                np.random.seed(seed=self.random_state)
-            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)
         lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
                        lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2,
                        lambda_neighborhood_g1=lambda_neighborhood_g1, lambda_ct_islands=lambda_ct_islands,
@@ -154,6 +183,16 @@ class Mapper:
                                     ("lambda_getis_ord", lambda_getis_ord), ("lambda_moran", lambda_moran),
                                     ("lambda_geary", lambda_geary)) if on]
         sharded, self._world, self._rank = _shard_context(distributed, group, blockers)
+        if sharded:
+            _check_same_problem(group, self.device, [S_train.shape[0], S_train.shape[1], G_train.shape[0], 0,
+                                                     d is not None, d_source is not None] + [bool(v) for v in lambdas.values()])
+        if M_init is None:
+            seed = self.random_state
+            if sharded and not seed:
+                seed = _shared_seed(group, self.device)
+            if seed:                                         # reference :148-150 (seed 0 / None => unseeded)
+                np.random.seed(seed=seed)
+            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)
         self._sharded = None
         if sharded:
             from .sharded import make_sharded
@@ -206,8 +245,10 @@ class Mapper:
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
             if val_each is not None and (t - 1) % val_each == 0:
                 val_rows.append((self._sharded or eng).validate())   # reference :398-403: after optimizer.step() of epoch t-1
-        P_dev = self._sharded.result_full() if self._sharded is not None else eng.result()
-        output = P_dev.detach().cpu().numpy()                # reference :406-408
+        if self._sharded is not None:
+            output = self._sharded.result_full(host=True)    # block by block: no rank holds two full C x V copies on its GPU
+        else:
+            output = eng.result().detach().cpu().numpy()     # reference :406-408
         history = self._history_dict(hist[:num_epochs])
         for row in val_rows:
             for k, x in zip(_VAL_KEYS, row):
@@ -256,7 +297,7 @@ class MapperConstrained:
         gemm_precision="bf16x3",
         M_init=None,
         F_init=None,
-        distributed=None,
+        distributed=False,
         group=None,
     ):
         if adata_map is not None:
@@ -270,15 +311,21 @@ class MapperConstrained:
         self.lambda_d, self.lambda_g1, self.lambda_g2, self.lambda_r = lambda_d, lambda_g1, lambda_g2, lambda_r
         self.lambda_count, self.lambda_f_reg = lambda_count, lambda_f_reg
         self.target_count = G.shape[0] if target_count is None else target_count          # :480-483
-        if M_init is None or F_init is None:
-            if self.random_state:                                                          # :473-474
-                np.random.seed(seed=self.random_state)
-            np.random.normal(0, 1, (S.shape[0], G.shape[0]))                               # :475 (first draw is discarded by :485)
-            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)   # :485
-            F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)                 # :490
         lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
                        lambda_r=lambda_r, lambda_count=lambda_count, lambda_f_reg=lambda_f_reg)
         sharded, self._world, self._rank = _shard_context(distributed, group, [])
+        if sharded:
+            _check_same_problem(group, self.device, [S.shape[0], S.shape[1], G.shape[0], 1, d is not None, 0] +
+                                [bool(v) for v in lambdas.values()])
+        if M_init is None or F_init is None:
+            seed = self.random_state
+            if sharded and not seed:                                                       # (every rank must draw the same M and F)
+                seed = _shared_seed(group, self.device)
+            if seed:                                                                       # :473-474
+                np.random.seed(seed=seed)
+            np.random.normal(0, 1, (S.shape[0], G.shape[0]))                               # :475 (first draw is discarded by :485)
+            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)   # :485
+            F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)                 # :490
         self._sharded = None
         if sharded:
             from .sharded import make_sharded
@@ -310,7 +357,10 @@ class MapperConstrained:
             if print_each and (t - 1) % print_each == 0 and not (self._sharded is not None and self._rank != 0):
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES_CONSTRAINED])
-        P, F = self._sharded.result_full(with_filter=True) if self._sharded is not None else eng.result(with_filter=True)
+        if self._sharded is not None:
+            P, F = (torch.as_tensor(x) for x in self._sharded.result_full(with_filter=True, host=True))
+        else:
+            P, F = eng.result(with_filter=True)
         h = hist[:num_epochs].detach().cpu().numpy()
         cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_COUNT, _capi.H_FREG]
         active = [True, True, bool(self.lambda_g2), bool(self.target_density_enabled and self.lambda_d), bool(self.lambda_r), True, True]

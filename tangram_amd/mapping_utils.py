@@ -112,12 +112,10 @@ def adata_to_cluster_expression(adata, cluster_label, scale=True, add_density=Tr
         X_new = _cluster_sums_on_device(X, labels, list(unique_labels), scale, device)
     else:
         X_new = np.empty((len(unique_labels), adata.shape[1]))
-    for index, l in enumerate(unique_labels):
-        if device is not None:
-            break
-        rows = np.where(labels == l)[0]
-        sub = X[rows]
-        X_new[index] = np.asarray(sub.mean(axis=0) if not scale else sub.sum(axis=0)).reshape(-1)
+        for index, l in enumerate(unique_labels):
+            rows = np.where(labels == l)[0]
+            sub = X[rows]
+            X_new[index] = np.asarray(sub.mean(axis=0) if not scale else sub.sum(axis=0)).reshape(-1)
     if add_density:
         new_obs["cluster_density"] = new_obs[cluster_label].map(lambda i: value_counts[i])
     new_obs.index = new_obs.index.astype(str)
@@ -154,10 +152,14 @@ def map_cells_to_space(
     *,
     gemm_precision="bf16x3",
     keep_mapper=False,
+    distributed=False,
+    group=None,
 ):
     """Map single cell data (`adata_sc`) on spatial data (`adata_sp`); see the reference docstring (:169-203).
 
-    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer); `keep_mapper=True` leaves the trained mapper on the
+    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer); `distributed=True` (+ optional `group`): shard the spots over
+    the ranks of an initialised torch.distributed process group -- opt-in, the same call on every rank, every rank gets the full
+    result (tangram_amd.mapping_optimizer); `keep_mapper=True` leaves the trained mapper on the
     result as `adata_map._tangram_amd_mapper` so that `tangram_amd.project_genes(..., mapper=adata_map._tangram_amd_mapper)`
     can project with the mapping still resident in HBM.  Default False: like the reference, the result owns no device
     memory -- the logits, both Adam moments, X and the workspace (>= 16 bytes per cell x spot) are released before returning."""
@@ -251,7 +253,7 @@ def map_cells_to_space(
         logging.info("Begin training with {} genes and {} density_prior in {} mode...".format(
             len(training_genes), d_str, mode))
         mapper = mo.Mapper(S=S, G=G, d=d, device=device, random_state=random_state, gemm_precision=gemm_precision,
-                           **hyperparameters)                                 # :355-357
+                           distributed=distributed, group=group, **hyperparameters)   # :355-357
         mapping_matrix, training_history = mapper.train(
             learning_rate=learning_rate, num_epochs=num_epochs, print_each=print_each)   # :361-363
     else:
@@ -262,7 +264,8 @@ def map_cells_to_space(
         logging.info("Begin training with {} genes and {} density_prior in {} mode...".format(
             len(training_genes), d_str, mode))
         mapper = mo.MapperConstrained(S=S, G=G, d=d, device=device, random_state=random_state,
-                                      gemm_precision=gemm_precision, **hyperparameters)       # :383-385
+                                      gemm_precision=gemm_precision, distributed=distributed, group=group,
+                                      **hyperparameters)                      # :383-385
         mapping_matrix, F_out, training_history = mapper.train(
             learning_rate=learning_rate, num_epochs=num_epochs, print_each=print_each)   # :387-389
 

@@ -80,6 +80,10 @@ class ShardedMapperEngine:
         self.lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0)
         self.lam.update(lambdas or {})
         self.mode = mode
+        if F0 is not None and self.world > 1:
+            # the filter logits are REPLICATED: every rank must start from rank 0's values (a caller that draws F0 per rank from
+            # an unseeded RNG would otherwise gate the all-reduced statistics differently on every rank and silently diverge)
+            F0 = self._from_rank0(F0, torch.device(device))
         self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, F0=F0, mode=mode, device=device,
                                    precision=precision, lambdas=self.lam, n_spots_total=n_spots_total, n_ranks=self.world,
                                    fwd_splits=fwd_splits, tile_size=tile_size, target_count=target_count)
@@ -113,6 +117,19 @@ class ShardedMapperEngine:
             raise ValueError("transport must be 'auto', 'rccl' or 'callbacks'")
         self._comm = handle
         self._attach()
+
+    def _from_rank0(self, x, device):
+        """`x` as held by rank 0, on every rank (float32 device tensor)."""
+        t = x.detach().to(device=device, dtype=torch.float32).contiguous().clone() if isinstance(x, torch.Tensor) else \
+            torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)), device=device)
+        if hasattr(self.pycomm, "broadcast"):
+            backend_cpu = isinstance(self.pycomm, DistComm) and dist.get_backend(self.group) != "nccl" and t.is_cuda
+            buf = t.cpu() if backend_cpu else t
+            self.pycomm.broadcast(buf, 0)
+            return buf.to(device)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.pycomm.all_gather(outs, t)
+        return outs[0]
 
     # -- callback transport -----------------------------------------------------------------------------------------------
     def _cb_all_reduce(self, ctx, buf, n, stream):
@@ -161,14 +178,36 @@ class ShardedMapperEngine:
         """Kept for callers of the earlier API: the rows written by `run` are already the global history."""
         return history
 
-    def result_full(self, with_filter=False):
-        """All-gather the column blocks of softmax(M) -> [C, V_total] on every rank (+ the replicated filter)."""
+    def result_full(self, with_filter=False, host=False):
+        """The column blocks of softmax(M) of every rank -> [C, V_total] on every rank (+ the replicated filter).
+        `host=True`: a NumPy array assembled block by block (one rank's block is broadcast at a time), so that no GPU ever holds
+        more than its own block plus one peer's -- for problems whose full mapping does not fit beside the training state."""
         if with_filter:
             P_local, F = self.eng.result(with_filter=True)
         else:
             P_local, F = self.eng.result(), None
-        P = self._gather_columns(P_local)
+        P = self._gather_columns_host(P_local) if host else self._gather_columns(P_local)
+        if host and F is not None:
+            F = F.detach().cpu().numpy()
         return (P, F) if with_filter else P
+
+    def _gather_columns_host(self, X_local):
+        bounds = [shard_bounds(self.n_spots_total, self.world, r) for r in range(self.world)]
+        if not hasattr(self.pycomm, "broadcast"):
+            return self._gather_columns(X_local).detach().cpu().numpy()
+        out = np.empty((X_local.shape[0], self.n_spots_total), dtype=np.float32)
+        cpu_backend = isinstance(self.pycomm, DistComm) and dist.get_backend(self.group) != "nccl"
+        for r, (lo, hi) in enumerate(bounds):
+            if r == self.rank:
+                blk = X_local.contiguous()
+            else:
+                blk = torch.empty((X_local.shape[0], hi - lo), dtype=torch.float32, device=X_local.device)
+            if cpu_backend and blk.is_cuda:
+                blk = blk.cpu()
+            self.pycomm.broadcast(blk, r)
+            out[:, lo:hi] = blk.detach().cpu().numpy()
+            del blk
+        return out
 
     def project_full(self, S_all=None, unfiltered=True):
         """softmax(M)^T S for every spot: each rank projects onto its own spots, the row blocks are gathered -> [V_total, K]."""

@@ -91,6 +91,18 @@ def project_genes(adata_map, adata_sc, cluster_label=None, scale=True, *, mapper
         engine, rows = mapper._engine, None
     if engine.C != S_all.shape[0]:
         raise ValueError("The two AnnDatas need to have same `obs` index.")
+    if not own:
+        # the trained mapper projects through its own seam: on a spot-sharded run that gathers every rank's block of spots
+        # (mapper._engine alone is only the LOCAL shard); MapperConstrained: softmax(M) without the filter, like adata_map.X
+        try:
+            X_space = mapper.project_genes_device(S_all, unfiltered=True)
+        except TypeError:
+            X_space = mapper.project_genes_device(S_all)
+        X_space = X_space.cpu().numpy()
+        adata_ge = _result(X_space, adata_map.var, adata_sc.var, adata_sc.uns)
+        training_genes = adata_map.uns["train_genes_df"].index.values
+        adata_ge.var["is_training"] = adata_ge.var.index.isin(training_genes)
+        return adata_ge
     if rows is not None and np.abs(rows - 1.0).max() > 1e-6:                         # not row-stochastic: P^T S = (P / r)^T (r S)
         if hasattr(S_all, "tocsr"):
             import scipy.sparse as sp

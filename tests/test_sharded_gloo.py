@@ -105,15 +105,15 @@ def test_two_shards_match_single_and_oracle(tmp_path):
     assert np.linalg.norm(z["Gc"] - ref) / np.linalg.norm(ref) < 1e-5
 
 
-def _val_each_run(device):
-    """`Mapper(...).train(val_each=2)` (the tuning path, mapping_parameter_tuning.py:110-129); under a process group the
+def _val_each_run(device, distributed=False):
+    """`Mapper(...).train(val_each=2)` (the tuning path, mapping_parameter_tuning.py:110-129); on spot shards the
     validation metrics are sums over ALL spots (tg_mapper_validate all-reduces them)."""
     import tangram_amd.mapping_optimizer as mo
     from oracle import tangram_oracle as orc
     C, K, V = 60, 16, 140
     data = orc.make_synthetic(C, K, V, seed=8)
     m = mo.Mapper(S=data["S"], G=data["G"], d=data["d"], lambda_d=1, lambda_g1=1, lambda_g2=0.5, device=device, random_state=7,
-                  gemm_precision="fp32")
+                  gemm_precision="fp32", distributed=distributed)
     P, hist = m.train(num_epochs=5, learning_rate=0.1, print_each=None, val_each=2)
     out = {"val_P": P}
     for k in hist:
@@ -136,22 +136,45 @@ def _seam_worker(rank, world, port, sim_path, outdir):
         for mode, kw in (("cells", {}), ("clusters", dict(cluster_label="subclass_label")), ("constrained", dict(target_count=9))):
             ad_sc, ad_sp = _adatas(C=70, K=14, V=150)
             ad_map = tg.map_cells_to_space(ad_sc, ad_sp, mode=mode, device="cpu", num_epochs=5, random_state=42, verbose=False,
-                                           gemm_precision="fp32", lambda_g2=0.4, **kw)
+                                           gemm_precision="fp32", lambda_g2=0.4, distributed=True, **kw)
             out[mode + "_X"] = ad_map.X
             out[mode + "_score"] = ad_map.uns["train_genes_df"]["train_score"].sort_index().to_numpy()
             out[mode + "_loss"] = np.array([float(x) for x in ad_map.uns["training_history"]["total_loss"]])
             if mode == "constrained":
                 out["constrained_F"] = np.asarray(ad_map.obs["F_out"])
-        out.update(_val_each_run("cpu"))
+        out.update(_val_each_run("cpu", distributed=True))
+        # sharding is opt-in: under the same process group, a mapper built WITHOUT distributed=True stays on its own device and
+        # issues no collective (rank 1 trains a different problem than rank 0 here: a hang or a mismatch would show)
+        import tangram_amd.mapping_optimizer as mo
+        from oracle import tangram_oracle as orc
+        own = orc.make_synthetic(40 + 7 * rank, 10, 90 + 5 * rank, seed=rank)
+        m_own = mo.Mapper(S=own["S"], G=own["G"], d=own["d"], lambda_d=1, device="cpu", random_state=3 + rank, gemm_precision="fp32")
+        assert m_own._sharded is None
+        out["own_P"], _ = m_own.train(num_epochs=2, print_each=None)
+        # an UNSEEDED sharded constrained run: every rank must slice the same draw of M and F (the seed comes from rank 0)
+        ad_sc, ad_sp = _adatas(C=70, K=14, V=150)
+        for rs in (None, 0):
+            ad_u = tg.map_cells_to_space(ad_sc, ad_sp, mode="constrained", device="cpu", num_epochs=4, random_state=rs, verbose=False,
+                                         gemm_precision="fp32", target_count=9, distributed=True)
+            out[f"unseeded_{rs}_X"] = ad_u.X
+            out[f"unseeded_{rs}_F"] = np.asarray(ad_u.obs["F_out"])
+            out[f"unseeded_{rs}_loss"] = np.array([float(x) for x in ad_u.uns["training_history"]["total_loss"]])
+        # ranks that disagree about the problem are told so (on every rank) instead of hanging in a collective
+        bad = orc.make_synthetic(30, 8, 60 + rank, seed=1)
+        try:
+            mo.Mapper(S=bad["S"], G=bad["G"], d=bad["d"], lambda_d=1, device="cpu", random_state=1, gemm_precision="fp32", distributed=True)
+            out["mismatch_raised"] = np.array(0)
+        except ValueError as e:
+            out["mismatch_raised"] = np.array(int("different problem" in str(e)))
         np.savez(os.path.join(outdir, f"seam_{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()
 
 
 def test_map_cells_to_space_shards_over_the_process_group(tmp_path):
-    """`map_cells_to_space` / `Mapper` / `MapperConstrained` under an initialised process group of 2 ranks shard the spots
-    (reference seam mapping_utils.py:355-389 carries only `device`): every rank gets the full mapping, equal to the
-    single-process run of the same call."""
+    """`map_cells_to_space(..., distributed=True)` / `Mapper` / `MapperConstrained` under an initialised process group of 2 ranks
+    shard the spots (reference seam mapping_utils.py:355-389 carries only `device`): every rank gets the full mapping, equal to
+    the single-process run of the same call.  Also: opt-in only, unseeded runs, and ranks that disagree about the problem."""
     sim_path = build_sim()
     if sim_path is None:
         pytest.skip("host clang not available to build the emulator")
@@ -184,5 +207,13 @@ def test_map_cells_to_space_shards_over_the_process_group(tmp_path):
                 np.testing.assert_allclose(z[k], single[k], rtol=5e-6, atol=1e-7, err_msg=k)
         for k in keys:
             np.testing.assert_array_equal(z0[k], z1[k])
+        assert z0["own_P"].shape == (40, 90) and z1["own_P"].shape == (47, 95)        # opt-in: independent per-rank mappers
+        assert int(z0["mismatch_raised"]) == 1 and int(z1["mismatch_raised"]) == 1
+        for rs in ("None", "0"):                                                       # unseeded sharded run: one consistent mapping
+            np.testing.assert_array_equal(z0[f"unseeded_{rs}_X"], z1[f"unseeded_{rs}_X"])
+            np.testing.assert_array_equal(z0[f"unseeded_{rs}_F"], z1[f"unseeded_{rs}_F"])
+            np.testing.assert_array_equal(z0[f"unseeded_{rs}_loss"], z1[f"unseeded_{rs}_loss"])
+            np.testing.assert_allclose(z0[f"unseeded_{rs}_X"].sum(axis=1), 1.0, atol=1e-5)
+            assert np.isfinite(z0[f"unseeded_{rs}_loss"]).all()
     finally:
         _capi._install_library_for_tests(None)
