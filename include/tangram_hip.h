@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 typedef enum tg_status {
     TG_OK = 0,
@@ -76,6 +76,10 @@ typedef struct tg_config {
     int32_t n_ranks;         /* 0 = the handle holds every spot and steps alone; >= 1 = it is one spot shard (one per GPU) and will be
                                 stepped through a communicator of that many ranks.  Sizes the gather buffer of the per-cell softmax
                                 statistics ([n_ranks][2 C + 64] floats of workspace).                                               */
+    int32_t bwd_tile;        /* 0 = the library's fixed rule; 128 or 256 = tile edge of the backward GEMM under the 256 layout (tuning /
+                                tests).  The stored product X is bit-identical for both; the row-dot partials of a spot shard depend on
+                                the tile width, which is why the rule is a function of the shape alone (never of a timing).            */
+    int32_t spot_offset;     /* spot shard: index of this shard's first spot among the n_spots_total spots (0 on one GPU)            */
 } tg_config;
 
 typedef struct tg_sizes {
@@ -149,10 +153,8 @@ void tg_mapper_destroy(tg_mapper* m);
 /* Replaces the body of Mapper.train / MapperConstrained.train (mapping_optimizer.py:382-396, :621-634):
  * runs n_steps iterations (loss, backward, Adam) with learning rate lr; writes one history row per step
  * into history_dev[(first_row + i) * TG_H_NTERMS ...] (device memory, may be NULL).
- * Asynchronous on the handle's stream, with one exception: the FIRST step of a handle whose layout uses 256-wide tiles and
- * whose tile_size is 0 times the backward GEMM on both tile sizes (a few launches, one hipEventSynchronize) and keeps the
- * faster; results do not depend on the choice.  Skipped (256^2 tiles kept) while the stream is being captured into a HIP
- * graph; TANGRAM_AMD_BWD_TILE=128|256 in the environment or a non-zero tg_config.tile_size pin the choice without timing.  */
+ * Asynchronous on the handle's stream: nothing in it synchronises, times or queries the device, so a call can be captured into a
+ * HIP graph from the first step on (the kernel selection is a fixed function of the configuration, tg_config.bwd_tile).  */
 int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row);
 
 /* Spot-sharded multi-GPU run: attach a communicator to a handle created with n_spots < n_spots_total (collective; performs the

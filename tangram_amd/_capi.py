@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtangram_hip.so")      # the in-tree build, nothing else (experiments: scripts/with_lib.py)
 
-TG_ABI_VERSION = 2
+TG_ABI_VERSION = 3
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 H_NTERMS = 16
@@ -29,7 +29,8 @@ class TgConfig(ct.Structure):
                  "lambda_count", "lambda_f_reg", "target_count", "lambda_neighborhood_g1", "lambda_ct_islands")] + \
                [(n, ct.c_int32) for n in ("n_cell_types", "nnz_w", "nnz_n")] + \
                [(n, ct.c_float) for n in ("lambda_getis_ord", "lambda_moran", "lambda_geary")] + [("nnz_s", ct.c_int32)] + \
-               [(n, ct.c_float) for n in ("beta1", "beta2", "eps")] + [("n_ranks", ct.c_int32)]
+               [(n, ct.c_float) for n in ("beta1", "beta2", "eps")] + \
+               [(n, ct.c_int32) for n in ("n_ranks", "bwd_tile", "spot_offset")]
 
 
 ALL_REDUCE_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_void_p)                 # tg_all_reduce_sum_fn

@@ -108,6 +108,7 @@ extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 #define TG_MAX_BANDS 16
+static constexpr int TG_ROWPASS_MAX_V = 16384;        // tg_adam_rowpass: 512 threads x 8 float4 per array
 #ifndef TG_FWD_WIDE
 #define TG_FWD_WIDE 1                                 // forward GEMM on 128 x 512 tiles where the 256^2 geometry would be used and Kp % 512 == 0
 #endif
@@ -120,7 +121,7 @@ struct TgLayout {
         o_accmpart, o_accm, o_actnorm, total;
     int T_ct, Tp, has_nb, has_ct, has_ac, bands, nranks;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
-    int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_tune_bwd)
+    int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
@@ -181,7 +182,20 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->Cr = (int)rup(L->C, L->T);
     L->nvt = L->Vr / L->T; L->nct = L->Cr / L->T; L->nkt = L->Kp / L->T;
     L->fwd_wide = (TG_FWD_WIDE && L->T == 256 && L->Kp % 512 == 0 && cfg->precision == TG_PREC_BF16X3) ? 1 : 0;   // (measured: plain bf16 is faster on 256^2, profiles/r02/run8_wide)
+    // Tile edge of the backward GEMM.  Under the 256 layout both 256^2 (one workgroup per CU) and 128^2 (two) are legal; the choice
+    // is a FIXED function of the shape (round 2 timed both on the first step: a hidden host synchronisation inside tg_mapper_step
+    // and a box-dependent kernel choice).  With the dense XCD-banded tile map 256^2 wins or ties every X-only shape measured
+    // (profiles/r02/run10_tiles + run11_dense_map).  The row-dot epilogue (spot shards, rows beyond TG_ROWPASS_MAX_V) takes 128^2
+    // tiles when the 256^2 grid is under 4 rounds of workgroups with a last round under 40 % full (1/8 shard of cfg2: 590 tiles =
+    // 2.3 rounds, 242 -> 222 us; at 4.6 and 9.2 rounds 256^2 wins).  cfg->bwd_tile pins it.
+    if (cfg->bwd_tile != 0 && cfg->bwd_tile != 128 && cfg->bwd_tile != 256) return tg_fail(TG_ERR_INVALID, "bwd_tile must be 0, 128 or 256");
     L->bwd_T = L->T;
+    if (L->T == 256) {
+        const bool rowdot = (cfg->n_ranks >= 1) || (L->Vtot != L->V) || (L->V > TG_ROWPASS_MAX_V);
+        const double rounds = (double)L->nct * (double)L->nvt / 256.0, frac = rounds - (double)(long)rounds;
+        if (cfg->bwd_tile) L->bwd_T = cfg->bwd_tile;
+        else if (rowdot && rounds < 4.0 && frac > 0.0 && frac < 0.4) L->bwd_T = 128;
+    }
     L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
@@ -297,7 +311,6 @@ struct tg_mapper {
     // history scalars deferred from tg_launch_loss to one extra workgroup of the next update kernel (tg_dghat_emit<SELF>)
     bool stream_once;                                // the per-iteration arrays exceed the MALL: non-temporal accesses (tg_ld_stream)
     bool fin_pending;
-    bool bwd_tuned;                                  // tg_tune_bwd has run
     TgFinalizeArgs fin_args;
     tg_comm* comm;                                   // spot-sharded run: the communicator (borrowed), else null
     // profiling
@@ -325,8 +338,6 @@ static void tg_prof_mark(tg_mapper* m, const char* name) {
 #endif
     m->prof_names.push_back(name);
 }
-
-static constexpr int TG_ROWPASS_MAX_V = 16384;        // tg_adam_rowpass: 512 threads x 8 float4 per array
 
 template <class PR, class GE>
 static int tg_lds_attr() {
@@ -569,7 +580,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     m->cfg = *cfg; m->L = L;
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
-    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->bwd_tuned = false; m->comm = nullptr;
+    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->comm = nullptr;
     // M, Adam m, v (fp32) and X (fp32 or bf16) of this handle against the 256 MB MALL, with room left for the GEMM operands
     m->stream_once = (size_t)L.C * L.Vp * (12 + (cfg->precision == TG_PREC_BF16 ? 2 : 4)) > ((size_t)192 << 20);
     m->s_adam = nullptr; m->s_fwd = nullptr;
@@ -792,7 +803,7 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
     int grid;
     // (the cached-access variant exists for the single-GPU X-only epilogue only: the row-dot variants serve spot shards and
     //  very long rows, i.e. big problems, and every GEMM instantiation costs seconds of compile time)
-    // ct0, ct1 count tiles of L.T cells; under the 256 layout the kernel may run on 128^2 tiles (L.bwd_T, see tg_tune_bwd)
+    // ct0, ct1 count tiles of L.T cells; under the 256 layout the kernel may run on 128^2 tiles (L.bwd_T, see tg_make_layout)
     const int f = L.T / L.bwd_T;
     const TgBwdArgs a = tg_bwd_args<PR>(m, f * ct0, f * ct1, &grid, L.bwd_T);
 #define TG_BWD_GO(GE, F, R, S) TG_LAUNCH((tg_bwd_kernel<PR, GE, F, R, S>), grid, 1, GE::NT, GE::BWD_LDS_BYTES, stream, a)
@@ -806,53 +817,6 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
         else TG_BWD_GO(TgGeoSmall, false, true, true);
     }
 #undef TG_BWD_GO
-}
-
-// Which tile geometry for the backward GEMM of THIS problem on THIS device: under the 256 layout both 256^2 (one workgroup per CU)
-// and 128^2 (two) are legal, and which one wins depends on how the tile count quantises into rounds of workgroups and on the
-// operand reuse in L2 (measured, profiles/r02/run10_tiles: 30k x 1k x 10k 256^2 by 4 %, 10k x 1k x 10k and 20k x 2k x 3k 128^2 by
-// 15 - 17 %).  Timed once per handle, on the first step, with the real operands in place (X-only epilogue: the result is bit-
-// identical for both geometries, every element is the same k-ordered sum).  TANGRAM_AMD_BWD_TILE=128|256 pins it (also for the
-// row-dot paths of spot shards, which are not timed: their partial sums depend on the tile width).
-template <class PR>
-static void tg_tune_bwd(tg_mapper* m, bool x_only) {
-    TgLayout& L = m->L;
-    if (m->bwd_tuned) return;
-    m->bwd_tuned = true;
-    if (L.T != 256 || L.bands > 1) return;
-    const char* pin = getenv("TANGRAM_AMD_BWD_TILE");
-    if (pin && *pin) { const int t = atoi(pin); if (t == 128 || t == 256) L.bwd_T = t; return; }
-    if (m->cfg.tile_size != 0) return;
-    if (!x_only) {
-        // row-dot epilogue (spot shards, very long rows): a fixed rule, so that a shape always takes the same summation order.
-        // 128^2 tiles when the 256^2 grid is a few rounds of workgroups with a thin last one (1/8 spot shard of 30k x 1k x 10k:
-        // 590 tiles = 2.3 rounds, 242 -> 222 us; at 4.6 and 9.2 rounds 256^2 wins: profiles/r02/run10_tiles, run11)
-        const double rounds = (double)L.nct * (double)L.nvt / 256.0, frac = rounds - (double)(long)rounds;
-        if (rounds < 4.0 && frac > 0.0 && frac < 0.4) L.bwd_T = 128;
-        return;
-    }
-#ifndef TG_SIM
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;             // (a stream under graph capture must not be synchronised:
-    if (hipStreamIsCapturing(m->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;   //  stay on 256^2)
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
-    float best = 3.0e38f;
-    int best_T = 256;
-    for (int t = 256; t >= 128; t -= 128) {
-        L.bwd_T = t;
-        tg_launch_bwd<PR>(m, m->stream, 0, L.nct, true);                       // warm-up (code object, L2)
-        (void)hipEventRecord(e0, m->stream);
-        for (int r = 0; r < 2; ++r) tg_launch_bwd<PR>(m, m->stream, 0, L.nct, true);
-        (void)hipEventRecord(e1, m->stream);
-        float ms = 3.0e38f;
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best_T = 256; break; }
-        if (ms < best * (t == 128 ? 0.98f : 1.f)) { best = ms; best_T = t; }   // (128 has to win by 2 %: ties stay on 256)
-    }
-    L.bwd_T = best_T;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-#else
-    (void)x_only;
-#endif
 }
 
 static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1) {
@@ -900,7 +864,6 @@ static TgUpdateArgs tg_update_args(tg_mapper* m, float lr, bool finalize, int c0
 template <class PR>
 static int tg_launch_rowdots(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
-    tg_tune_bwd<PR>(m, false);
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);
     tg_prof_mark(m, "tg_bwd_kernel");
     tg_launch_rowsum(m, m->stream, 0, L.C);
@@ -965,7 +928,6 @@ static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     if (m->L.V <= TG_ROWPASS_MAX_V) {
         // a row of M and X fits the registers of one workgroup: the backward GEMM only stores X, the row dots are fused
         // into the update (tg_adam_rowpass), which also leaves the regulariser row sums for tg_hist_regs / the filter
-        tg_tune_bwd<PR>(m, true);
         tg_launch_bwd<PR>(m, m->stream, 0, m->L.nct, true);
         tg_prof_mark(m, "tg_bwd_kernel");
         if (tg_launch_failed()) return tg_launch_status();       // stop at the first failed launch, named
@@ -1329,7 +1291,6 @@ static int tg_one_step_sharded(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     if ((rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;                                    // (coefficients; dGhat operand image)
-    tg_tune_bwd<PR>(m, false);
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);                                                // X + row-dot partials of this rank's spots
     tg_prof_mark(m, "tg_bwd_kernel");
     tg_launch_rowsum(m, m->stream, 0, L.C);

@@ -39,6 +39,7 @@ class HipMapperEngine:
 
     def __init__(self, S, G, M0, d=None, d_source=None, F0=None, *, mode="mapper", device="cuda:0",
                  precision="bf16x3", lambdas=None, n_spots_total=None, n_ranks=0, fwd_splits=0, tile_size=0, pipeline_bands=0,
+                 bwd_tile=0, spot_offset=0,
                  target_count=0.0, betas=(0.9, 0.999), eps=1e-8,
                  voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
         self.device = torch.device(device)
@@ -77,6 +78,8 @@ class HipMapperEngine:
         cfg.fwd_splits = int(fwd_splits)
         cfg.tile_size = int(tile_size)
         cfg.pipeline_bands = int(pipeline_bands)
+        cfg.bwd_tile = int(bwd_tile)
+        cfg.spot_offset = int(spot_offset)
         for k, v in lam.items():
             setattr(cfg, k, float(v))
         cfg.target_count = float(target_count)

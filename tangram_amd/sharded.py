@@ -69,8 +69,8 @@ def rccl_library_path():
 
 class ShardedMapperEngine:
     def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, F0=None, *, n_spots_total, device, mode="mapper",
-                 precision="bf16x3", lambdas=None, target_count=0.0, group=None, fwd_splits=0, tile_size=0, comm=None,
-                 transport="auto"):
+                 precision="bf16x3", lambdas=None, target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None,
+                 transport="auto", spot_offset=0):
         # `comm`: anything with world, rank, all_reduce, all_gather_into_tensor, all_gather (tests drive several shards of one
         # GPU through an in-process communicator); default: the torch.distributed group
         self.pycomm = comm if comm is not None else DistComm(group)
@@ -86,7 +86,8 @@ class ShardedMapperEngine:
             F0 = self._from_rank0(F0, torch.device(device))
         self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, F0=F0, mode=mode, device=device,
                                    precision=precision, lambdas=self.lam, n_spots_total=n_spots_total, n_ranks=self.world,
-                                   fwd_splits=fwd_splits, tile_size=tile_size, target_count=target_count)
+                                   fwd_splits=fwd_splits, tile_size=tile_size, bwd_tile=bwd_tile, target_count=target_count,
+                                   spot_offset=spot_offset)
         self.has_density = d_local is not None
         self.n_spots_total = int(n_spots_total)
         lib = self.eng._lib
@@ -238,7 +239,7 @@ class ShardedMapperEngine:
 
 
 def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapper", precision="bf16x3", lambdas=None,
-                 target_count=0.0, group=None, fwd_splits=0, tile_size=0, comm=None, transport="auto"):
+                 target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None, transport="auto"):
     """Slice full problem arrays (identical on every rank) into this rank's spot block."""
     pc = comm if comm is not None else DistComm(group)
     world, rank = pc.world, pc.rank
@@ -255,4 +256,4 @@ def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapp
     d_l = None if d is None else d[lo:hi]
     return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, F0, n_spots_total=V, device=device, mode=mode, precision=precision,
                                lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, tile_size=tile_size,
-                               comm=comm, transport=transport)
+                               bwd_tile=bwd_tile, comm=comm, transport=transport, spot_offset=lo)

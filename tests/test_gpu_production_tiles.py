@@ -122,10 +122,10 @@ def test_layout_boundaries_against_oracle_fp64(C, K, V, tile, wide, mode):
     e.release()
 
 
-def test_backward_tile_choice_does_not_change_the_result(monkeypatch):
-    """Under the 256 layout the backward GEMM runs on 256^2 or 128^2 tiles, whichever tg_tune_bwd times faster on the first step
-    (TANGRAM_AMD_BWD_TILE pins it): every X element is the same k-ordered sum, so mapping and history are bit-identical; and a
-    1-rank spot shard (row-dot epilogue) on either geometry matches the fp64 oracle."""
+def test_backward_tile_choice_does_not_change_the_result():
+    """Under the 256 layout the backward GEMM runs on 256^2 or 128^2 tiles (a fixed rule of the shape; `bwd_tile` pins it): every
+    X element is the same k-ordered sum, so mapping and history are bit-identical; and a 1-rank spot shard (row-dot epilogue) on
+    either geometry matches the fp64 oracle."""
     from tangram_amd.engine import HipMapperEngine
     from tangram_amd.sharded import make_sharded
     from tangram_amd import _capi
@@ -138,8 +138,8 @@ def test_backward_tile_choice_does_not_change_the_result(monkeypatch):
     o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
     Po, ho = o.train(n, 0.1)
 
-    def alone():
-        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam)
+    def alone(bwd_tile=0):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, bwd_tile=bwd_tile)
         assert e.cfg.tile_size == 0
         hist = e.new_history(n)
         e.step(n, 0.1, hist)
@@ -154,17 +154,16 @@ def test_backward_tile_choice_does_not_change_the_result(monkeypatch):
             assert err <= 1e-5 * max(1.0, np.abs(ref).max()), (what, k, err)
         assert np.abs(P - Po).max() <= 2e-4, what
 
-    monkeypatch.delenv("TANGRAM_AMD_BWD_TILE", raising=False)
     h_auto, P_auto = alone()
     check(h_auto, P_auto, "auto")
-    for pin in ("256", "128"):
-        monkeypatch.setenv("TANGRAM_AMD_BWD_TILE", pin)
-        h, P = alone()
+    for pin in (256, 128):
+        h, P = alone(pin)
         np.testing.assert_array_equal(P, P_auto)
         np.testing.assert_array_equal(h, h_auto)
 
         def rank_fn(comm):
-            sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, comm=comm)
+            sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, comm=comm,
+                              bwd_tile=pin)
             hh = sh.eng.new_history(n)
             sh.run(n, 0.1, hh)
             out = hh.cpu().numpy(), sh.result_full().cpu().numpy()
@@ -172,7 +171,7 @@ def test_backward_tile_choice_does_not_change_the_result(monkeypatch):
             return out
 
         (h1, P1), = run_ranks(1, rank_fn)
-        check(h1, P1, "1-rank shard, backward tiles " + pin)
+        check(h1, P1, f"1-rank shard, backward tiles {pin}")
 
 
 def _torch_reference(w, mode, M0, F0, steps):

@@ -85,8 +85,8 @@ def test_emulated_large_tile_geometry(sim, precision, K):
 
 
 @pytest.mark.parametrize("mode", ["mapper", "constrained"])
-def test_emulated_backward_on_small_tiles_under_the_256_layout(sim, mode, monkeypatch):
-    """TANGRAM_AMD_BWD_TILE=128: the backward GEMM of a 256-layout problem on 128^2 tiles (what tg_tune_bwd may pick on the GPU) --
+def test_emulated_backward_on_small_tiles_under_the_256_layout(sim, mode):
+    """bwd_tile=128: the backward GEMM of a 256-layout problem on 128^2 tiles (what the fixed rule picks for thin shard grids) --
     alone (X-only epilogue) and as a 1-rank spot shard (row-dot epilogue, twice the partials per row); against the fp64 oracle,
     and the X-only path bit-identical to the 256^2 run."""
     from tangram_amd.engine import HipMapperEngine
@@ -116,23 +116,22 @@ def test_emulated_backward_on_small_tiles_under_the_256_layout(sim, mode, monkey
             np.testing.assert_allclose(hist[:, col], ref, atol=1e-5 * max(1.0, np.abs(ref).max()), rtol=0, err_msg=k)
         assert np.abs(P - Po).max() < 2e-4
 
-    def alone():
-        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=256, **kw)
+    def alone(bwd_tile):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=256,
+                            bwd_tile=bwd_tile, **kw)
         hist = e.new_history(n)
         e.step(n, 0.1, hist)
         return hist.numpy().copy(), e.result().numpy().copy()
 
-    monkeypatch.setenv("TANGRAM_AMD_BWD_TILE", "256")
-    h256, P256 = alone()
-    monkeypatch.setenv("TANGRAM_AMD_BWD_TILE", "128")
-    h128, P128 = alone()
+    h256, P256 = alone(256)
+    h128, P128 = alone(128)
     check(h128, P128)
     np.testing.assert_array_equal(P128, P256)
     np.testing.assert_array_equal(h128, h256)
 
     def rank_fn(comm):
         sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=256,
-                          comm=comm, **kw)
+                          bwd_tile=128, comm=comm, **kw)
         h = sh.eng.new_history(n)
         sh.run(n, 0.1, h)
         return h.numpy(), sh.result_full().numpy()
