@@ -289,7 +289,7 @@ def main():
     run(1, hist)
     torch.cuda.synchronize(device)
     main_loss = float(hist[0, 1].item())
-    if not (main_loss == main_loss):
+    if not (main_loss == main_loss) and not os.environ.get("TG_BENCH_TIMING_ABLATION"):    # (ablation builds compute garbage on purpose)
         print("bench.py: the last step's main_loss is NaN", file=sys.stderr)
         sys.exit(3)
 
