@@ -1370,13 +1370,17 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
         if constexpr (X16) xr[q] = tg_ld_stream<STREAM>((const u32x2*)((const unsigned short*)a.X + row + vl));
         else xr[q] = tg_ld_stream<STREAM>((const f32x4*)((const float*)a.X + row + vl));
     }
-    f32x4 m1q[NQ], m2q[NQ];                              // the moments travel while pass 1 computes
+    // the moments travel while pass 1 computes -- except that the regularised variants at the 128-register limit (4 waves per SIMD,
+    // NT * NQ = 2560) request the second moment only behind the pass-1 sums, under the block reduction: all four arrays in flight
+    // at once left them 2 - 8 registers short (scratch spills in round 2)
+    constexpr bool LATE_M2 = FULL && STREAM && (NT * NQ == 2560);
+    f32x4 m1q[NQ], m2q[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int v = 4 * (t + NT * q);
         const int vl = v < a.V ? v : 0;
         m1q[q] = tg_ld_stream<STREAM>((const f32x4*)(a.am + row + vl));
-        m2q[q] = tg_ld_stream<STREAM>((const f32x4*)(a.av + row + vl));
+        if constexpr (!LATE_M2) m2q[q] = tg_ld_stream<STREAM>((const f32x4*)(a.av + row + vl));
     }
     float acc[NP];
 #pragma unroll
@@ -1405,6 +1409,13 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
                 acc[TGP1_L2 % NP] += mo * mo;
             }
             acc[TGP1_R] += p * dp;
+        }
+    }
+    if constexpr (LATE_M2) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int v = 4 * (t + NT * q);
+            m2q[q] = tg_ld_stream<STREAM>((const f32x4*)(a.av + row + (v < a.V ? v : 0)));
         }
     }
 #pragma unroll
@@ -1544,7 +1555,10 @@ struct TgGeneReduceArgs { const float* genepart; int nrb, Kp; float* genestat; }
 struct TgStepVar { float step_size, bc2_sqrt; long long hist_row; };    // hist_row < 0: no history wanted
 
 template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) { tg_fwd_body<PR, GE>(a); }
-template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel_b(const TgFwdArgs* argv) { tg_fwd_body<PR, GE>(argv[blockIdx.z]); }
+template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel_b(const TgFwdArgs* argv) {
+    const TgFwdArgs a = argv[blockIdx.z];            // (a by-value copy: referencing the block in memory cost the wide geometry 16 spilled registers)
+    tg_fwd_body<PR, GE>(a);
+}
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) { tg_ghat_reduce_body(a); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce_b(const TgGhatReduceArgs* argv) { tg_ghat_reduce_body(argv[blockIdx.z]); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body(genepart, nrb, Kp, genestat); }
@@ -1560,8 +1574,9 @@ template <class PR, class GE>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_bwd_kernel_b(const TgBwdArgs* argv) { tg_bwd_body<PR, GE, false, false, false>(argv[blockIdx.z]); }
 template <bool FULL, bool X16, int NQ, int NT, bool STREAM>
 TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass(TgUpdateArgs a) { tg_adam_rowpass_body<FULL, X16, NQ, NT, STREAM>(a); }
+// (batched: the argument block of the mapping lives in SGPRs, which leaves the 5-quad variant short at 128 VGPRs: 3 waves per SIMD there)
 template <bool FULL, bool X16, int NQ, int NT>
-TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ <= 2560 ? 4 : 2)) tg_adam_rowpass_b(const TgUpdateArgs* argv, TgStepVar var) {
+TG_KERNEL void TG_LAUNCH_BOUNDS2(NT, (NT * NQ < 2560 ? 4 : (NT * NQ == 2560 ? 3 : 2))) tg_adam_rowpass_b(const TgUpdateArgs* argv, TgStepVar var) {
     TgUpdateArgs a = argv[blockIdx.z];
     a.step_size = var.step_size; a.bc2_sqrt = var.bc2_sqrt;
     a.fin.hist = (var.hist_row >= 0 && a.fin.hist) ? a.fin.hist + var.hist_row * TGH_NTERMS : a.fin.coef;   // (no history: the row lands in the
