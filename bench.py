@@ -238,9 +238,6 @@ def main():
     if args.shape:
         C, K, V = (int(x) for x in args.shape.split(","))
     precision = args.precision or default_prec
-    if world > 1 and mode == "spatial":
-        print("bench.py: the spatial terms need the whole spot graph on one GPU (cfg5b is a 1-GPU configuration)", file=sys.stderr)
-        sys.exit(2)
     w = make_workload(C, K, V, device, seed=0)
     lr = 0.1
     extra = {}
@@ -262,13 +259,14 @@ def main():
             e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=prec, lambdas=lam,
                                 fwd_splits=args.splits, tile_size=args.tile, pipeline_bands=args.bands, **extra)
             return e, e, (lambda n, h=None: e.step(n, lr, h))
-        lo, hi = shard_bounds(V, world, rank)
+        lo, hi = shard_bounds(V, world, rank, mode == "spatial")      # (spatial terms: blocks of ceil(V / world) spots)
         M0 = init_logits(C, hi - lo, device, seed=42 + rank)
         kw = dict(extra)
         if mode == "constrained":
             kw["F0"] = torch.randn(C, device=device, generator=torch.Generator(device=device).manual_seed(7))
         sh = ShardedMapperEngine(w["S"], w["G"][lo:hi].contiguous(), M0, w["d"][lo:hi].contiguous(), n_spots_total=V,
-                                 device=device, precision=prec, lambdas=lam, fwd_splits=args.splits, tile_size=args.tile, **kw)
+                                 device=device, precision=prec, lambdas=lam, fwd_splits=args.splits, tile_size=args.tile,
+                                 spot_offset=lo, **kw)
         return sh, sh.eng, (lambda n, h=None: sh.run(n, lr, h))
 
     owner, core, run = make_engine(precision)

@@ -120,6 +120,11 @@ struct TgLayout {
         o_acY, o_acZ, o_acTg, o_acTm, o_acrefp, o_acr, o_acrc, o_acpart, o_acstat, o_acstat2, o_accoef, o_acB1, o_acD,
         o_accmpart, o_accm, o_actnorm, total;
     int T_ct, Tp, has_nb, has_ct, has_ac, bands, nranks;
+    // spatial terms: the spots their kernels run over.  One GPU: Vs = V.  Spot shard: Vs = ALL spots -- every rank gathers Ghat (and,
+    // once, G) and evaluates the spatial terms redundantly on the whole graph; shards are then blocks of Vmaxl = ceil(Vtot / ranks)
+    // spots (only the last one shorter), so that the gathered blocks ARE the global matrix.  Vsr = rows allocated (>= Vs).
+    int Vs, Vsr, Vmaxl, sp_shard, nrb_s;
+    size_t o_GhatFull, o_Gfull;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
     int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
@@ -168,8 +173,16 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->has_ac = cfg->lambda_getis_ord > 0.f || cfg->lambda_moran > 0.f || cfg->lambda_geary > 0.f;
     if (L->has_ac && cfg->nnz_s < 1) return tg_fail(TG_ERR_INVALID, "the spatial autocorrelation terms need the spatial_weights graph");
     if ((L->has_nb || L->has_ct || L->has_ac) && cfg->mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_INVALID, "spatial terms exist only in Mapper (mapping_utils.py:366-375 ignores them in constrained mode)");
-    if ((L->has_nb || L->has_ct || L->has_ac) && cfg->n_spots_total > 0 && cfg->n_spots_total != cfg->n_spots)
-        return tg_fail(TG_ERR_UNSUPPORTED, "spatial terms need the whole spot graph on one GPU (no halo exchange yet)");
+    const bool spatial = L->has_nb || L->has_ct || L->has_ac;
+    L->sp_shard = (spatial && (cfg->n_ranks >= 1 || L->Vtot != L->V)) ? 1 : 0;
+    if (L->sp_shard) {
+        if (cfg->n_ranks < 1) return tg_fail(TG_ERR_INVALID, "a spot shard with spatial terms needs n_ranks");
+        L->Vmaxl = (L->Vtot + cfg->n_ranks - 1) / cfg->n_ranks;
+        if (cfg->spot_offset < 0 || cfg->spot_offset % L->Vmaxl != 0 || cfg->spot_offset >= L->Vtot ||
+            L->V != ((L->Vtot - cfg->spot_offset < L->Vmaxl) ? L->Vtot - cfg->spot_offset : L->Vmaxl))
+            return tg_fail(TG_ERR_INVALID, "spatial terms on spot shards: shard r must hold the spots [r * ceil(V / ranks), ...) (got offset %d, %d of %d spots, %d ranks)",
+                           cfg->spot_offset, L->V, L->Vtot, cfg->n_ranks);
+    }
     if (L->has_ct && cfg->n_cell_types < 1) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs n_cell_types >= 1");
     if (L->has_nb && cfg->nnz_w < 1) return tg_fail(TG_ERR_INVALID, "lambda_neighborhood_g1 > 0 needs the voxel_weights graph");
     if (L->has_ct && cfg->nnz_n < 1) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs the neighborhood_filter graph");
@@ -197,6 +210,9 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
         else if (rowdot && rounds < 4.0 && frac > 0.0 && frac < 0.4) L->bwd_T = 128;
     }
     L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
+    L->Vs = L->sp_shard ? L->Vtot : L->V;
+    L->Vsr = L->sp_shard ? (int)rup((size_t)cfg->n_ranks * L->Vmaxl, TG_RB) : L->Vr;
+    L->nrb_s = (L->Vsr + TG_RB - 1) / TG_RB;
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
     const int slots = 256 * (L->T == 256 ? 1 : 2);
@@ -218,8 +234,9 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_St = take((size_t)L->Kp * L->Cp * L->ESZ);
     L->o_StP = take((size_t)L->Kp * L->Cp * L->ESZ);      // operand image of a block of genes handed to tg_mapper_project_genes
     L->o_dG = take((size_t)L->Vr * L->Kp * L->ESZ);
-    L->o_Gp = take((size_t)L->Vr * L->Kp * 4);
-    L->o_Ghat = take((size_t)L->Vr * L->Kp * 4);
+    const size_t vrows = (L->sp_shard && L->Vmaxl > L->Vr) ? (size_t)L->Vmaxl : (size_t)L->Vr;   // (a gathered block is Vmaxl rows)
+    L->o_Gp = take(vrows * L->Kp * 4);
+    L->o_Ghat = take(vrows * L->Kp * 4);
     L->o_Gpart = take((size_t)L->nsplit * L->Vr * L->Kp * 4);
     L->o_genepart = take((size_t)L->nrb * 2 * L->Kp * 4);
     L->o_genestat = take((size_t)2 * L->Kp * 4);
@@ -247,31 +264,35 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_X = take((size_t)L->C * L->Vp * 4);
     L->o_gfrac = take((size_t)L->Kp * 4);
     L->o_rowent = take((size_t)L->Cp * 4);
-    if (L->has_nb || L->has_ct || L->has_ac) L->o_extra = take((size_t)L->Vr * L->Kp * 4);
+    if (L->sp_shard) {
+        L->o_GhatFull = take((size_t)L->Vsr * L->Kp * 4);
+        L->o_Gfull = take((size_t)L->Vsr * L->Kp * 4);
+    }
+    if (L->has_nb || L->has_ct || L->has_ac) L->o_extra = take((size_t)L->Vsr * L->Kp * 4);
     if (L->has_nb) {
-        L->o_WG = take((size_t)L->Vr * L->Kp * 4);
-        L->o_Y = take((size_t)L->Vr * L->Kp * 4);
-        L->o_nbpart = take((size_t)L->nrb * 2 * L->Kp * 4);
+        L->o_WG = take((size_t)L->Vsr * L->Kp * 4);
+        L->o_Y = take((size_t)L->Vsr * L->Kp * 4);
+        L->o_nbpart = take((size_t)L->nrb_s * 2 * L->Kp * 4);
         L->o_nbstat = take((size_t)2 * L->Kp * 4);
         L->o_wgn2 = take((size_t)2 * L->Kp * 4);
         L->o_nbcoef = take((size_t)2 * L->Kp * 4);
     }
     if (L->has_ct) {
-        L->o_ctmask = take((size_t)L->Vr * L->Tp * 4);
-        L->o_ctpart = take((size_t)L->Vr * 4);
+        L->o_ctmask = take((size_t)L->Vsr * L->Tp * 4);
+        L->o_ctpart = take((size_t)L->Vsr * 4);
     }
     if (L->has_ac) {
-        const size_t vk = (size_t)L->Vr * L->Kp * 4, kp = (size_t)L->Kp * 4;
+        const size_t vk = (size_t)L->Vsr * L->Kp * 4, kp = (size_t)L->Kp * 4;
         L->o_acY = take(vk); L->o_acZ = take(vk); L->o_acTg = take(vk); L->o_acTm = take(vk); L->o_acB1 = take(vk); L->o_acD = take(vk);
-        L->o_acrefp = take(kp); L->o_acr = take((size_t)L->Vr * 4); L->o_acrc = take((size_t)L->Vr * 4);
-        L->o_acpart = take((size_t)L->nrb * TGAC_NSTAT * kp); L->o_acstat = take(TGAC_NSTAT * kp); L->o_acstat2 = take(3 * kp);
-        L->o_accoef = take(TGAC_NCOEF * kp); L->o_accmpart = take((size_t)L->nrb * kp); L->o_accm = take(kp); L->o_actnorm = take(4 * kp);
+        L->o_acrefp = take(kp); L->o_acr = take((size_t)L->Vsr * 4); L->o_acrc = take((size_t)L->Vsr * 4);
+        L->o_acpart = take((size_t)L->nrb_s * TGAC_NSTAT * kp); L->o_acstat = take(TGAC_NSTAT * kp); L->o_acstat2 = take(3 * kp);
+        L->o_accoef = take(TGAC_NCOEF * kp); L->o_accmpart = take((size_t)L->nrb_s * kp); L->o_accm = take(kp); L->o_actnorm = take(4 * kp);
     }
     for (int gph = 0; gph < 6; ++gph) {           // 0: W, 1: W^T, 2: N, 3: N^T, 4: Ws, 5: Ws^T
         const bool on = gph < 2 ? L->has_nb : (gph < 4 ? L->has_ct : L->has_ac);
         const size_t nnz = gph < 2 ? (size_t)cfg->nnz_w : (gph < 4 ? (size_t)cfg->nnz_n : (size_t)cfg->nnz_s);
         if (!on) continue;
-        L->o_csr[gph][0] = take((size_t)(L->V + 1) * 4);
+        L->o_csr[gph][0] = take((size_t)(L->Vs + 1) * 4);
         L->o_csr[gph][1] = take(nnz * 4);
         L->o_csr[gph][2] = take(nnz * 4);
     }
@@ -410,6 +431,10 @@ static TgCsr tg_csr(const tg_mapper* m, int gph) {
     return c;
 }
 
+// the Ghat / G the spatial terms are evaluated on: this handle's own, or (spot shard) the gathered global matrices
+static float* tg_sp_ghat(tg_mapper* m) { return m->L.sp_shard ? m->fp(m->L.o_GhatFull) : m->fp(m->L.o_Ghat); }
+static float* tg_sp_g(tg_mapper* m) { return m->L.sp_shard ? m->fp(m->L.o_Gfull) : m->fp(m->L.o_Gp); }
+
 // spatial terms, set-up: library-owned copies of the CSR graphs, W G and |W G_k|^2 (constant: :236 recomputes it every iteration)
 static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
     const TgLayout& L = m->L;
@@ -422,18 +447,25 @@ static int tg_setup_spatial(tg_mapper* m, const tg_inputs* in) {
         const size_t nnz = gph < 2 ? (size_t)m->cfg.nnz_w : (gph < 4 ? (size_t)m->cfg.nnz_n : (size_t)m->cfg.nnz_s);
         for (int j = 0; j < 3; ++j)
             if (!src[gph][j]) return tg_fail(TG_ERR_INVALID, "a spatial term is enabled but its CSR graph (or the transpose) is NULL");
-        TG_CK(tg_memcpy(m->ws + L.o_csr[gph][0], src[gph][0], (size_t)(L.V + 1) * 4, m->stream));
+        TG_CK(tg_memcpy(m->ws + L.o_csr[gph][0], src[gph][0], (size_t)(L.Vs + 1) * 4, m->stream));
         TG_CK(tg_memcpy(m->ws + L.o_csr[gph][1], src[gph][1], nnz * 4, m->stream));
         TG_CK(tg_memcpy(m->ws + L.o_csr[gph][2], src[gph][2], nnz * 4, m->stream));
     }
     if (L.has_ct && !in->ct_encode_dev) return tg_fail(TG_ERR_INVALID, "lambda_ct_islands > 0 needs ct_encode");
+    return TG_OK;
+}
+
+// ... and what is derived from G over ALL the spots the spatial terms see: W G and |W G_k|^2.  One GPU: at create.  Spot shard: at
+// tg_mapper_attach_comm, once the blocks of G have been gathered.
+static int tg_setup_spatial_derived(tg_mapper* m) {
+    const TgLayout& L = m->L;
     if (L.has_nb) {
         TgSpmmArgs a = {};
-        a.W = tg_csr(m, 0); a.A = m->fp(L.o_Gp); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
-        a.Y = m->fp(L.o_WG); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
-        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
-        const int nrb = (L.V + TG_RB - 1) / TG_RB;
-        TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_WG), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
+        a.W = tg_csr(m, 0); a.A = tg_sp_g(m); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
+        a.Y = m->fp(L.o_WG); a.V = L.Vs; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.Vs, 1, 256, 0, m->stream, a);
+        const int nrb = (L.Vs + TG_RB - 1) / TG_RB;
+        TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_WG), (const float*)m->fp(L.o_WG), L.Vs, L.Kp, m->fp(L.o_nbpart));
         TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_wgn2));
         TG_LAUNCH_CK();
     }
@@ -445,21 +477,21 @@ static int tg_launch_spatial_stats(tg_mapper* m) {
     const TgLayout& L = m->L;
     if (L.has_nb) {
         TgSpmmArgs a = {};
-        a.W = tg_csr(m, 0); a.A = m->fp(L.o_Ghat); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
-        a.Y = m->fp(L.o_Y); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
-        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
-        const int nrb = (L.V + TG_RB - 1) / TG_RB;
-        TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_Y), (const float*)m->fp(L.o_WG), L.V, L.Kp, m->fp(L.o_nbpart));
+        a.W = tg_csr(m, 0); a.A = tg_sp_ghat(m); a.B = nullptr; a.ca = nullptr; a.cb = nullptr;
+        a.Y = m->fp(L.o_Y); a.V = L.Vs; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.Vs, 1, 256, 0, m->stream, a);
+        const int nrb = (L.Vs + TG_RB - 1) / TG_RB;
+        TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)m->fp(L.o_Y), (const float*)m->fp(L.o_WG), L.Vs, L.Kp, m->fp(L.o_nbpart));
         TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_nbpart), nrb, L.Kp, m->fp(L.o_nbstat));
         tg_prof_mark(m, "tg_spatial_nb_stats");
     }
     if (L.has_ct) {
         TgCtArgs c;
-        c.N = tg_csr(m, 2); c.Ghat = m->fp(L.o_Ghat); c.mask = m->fp(L.o_ctmask); c.ctpart = m->fp(L.o_ctpart);
-        c.extra = m->fp(L.o_extra); c.V = L.V; c.Kp = L.Kp; c.K = L.K; c.T = L.T_ct; c.Tp = L.Tp; c.lambda_ct = m->cfg.lambda_ct_islands;
-        TG_LAUNCH(tg_ct_mask, L.V, 1, 64, 0, m->stream, c);
+        c.N = tg_csr(m, 2); c.Ghat = tg_sp_ghat(m); c.mask = m->fp(L.o_ctmask); c.ctpart = m->fp(L.o_ctpart);
+        c.extra = m->fp(L.o_extra); c.V = L.Vs; c.Kp = L.Kp; c.K = L.K; c.T = L.T_ct; c.Tp = L.Tp; c.lambda_ct = m->cfg.lambda_ct_islands;
+        TG_LAUNCH(tg_ct_mask, L.Vs, 1, 64, 0, m->stream, c);
         c.N = tg_csr(m, 3);
-        TG_LAUNCH(tg_ct_grad, L.V, 1, 64, 0, m->stream, c);
+        TG_LAUNCH(tg_ct_grad, L.Vs, 1, 64, 0, m->stream, c);
         tg_prof_mark(m, "tg_spatial_ct");
     }
     return TG_OK;
@@ -474,7 +506,7 @@ static TgAcArgs tg_ac_args(tg_mapper* m, const float* X, bool setup, float* hist
     a.part = m->fp(L.o_acpart); a.stat = m->fp(L.o_acstat); a.stat2 = m->fp(L.o_acstat2); a.coef = m->fp(L.o_accoef);
     a.B1 = m->fp(L.o_acB1); a.D = m->fp(L.o_acD); a.cmpart = m->fp(L.o_accmpart); a.cm = m->fp(L.o_accm);
     a.hist = hist_row ? hist_row : m->fp(L.o_scal);
-    a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.setup = setup ? 1 : 0;
+    a.V = L.Vs; a.Vr = L.Vsr; a.Kp = L.Kp; a.K = L.K; a.setup = setup ? 1 : 0;
     a.lam_getis = m->cfg.lambda_getis_ord; a.lam_moran = m->cfg.lambda_moran; a.lam_geary = m->cfg.lambda_geary;
     return a;
 }
@@ -482,10 +514,10 @@ static TgAcArgs tg_ac_args(tg_mapper* m, const float* X, bool setup, float* hist
 // Y = Ws X (+ local Geary sums into D), first and second stage statistics
 static void tg_ac_indicators(tg_mapper* m, TgAcArgs& a) {
     const TgLayout& L = m->L;
-    const int nrb = (L.V + TG_RB - 1) / TG_RB, kb = (L.Kp + 255) / 256;
+    const int nrb = (L.Vs + TG_RB - 1) / TG_RB, kb = (L.Kp + 255) / 256;
     TgSpmmArgs sp = {};
-    sp.W = tg_csr(m, 4); sp.A = a.X; sp.Y = m->fp(L.o_acY); sp.E = m->fp(L.o_acD); sp.V = L.V; sp.Kp = L.Kp; sp.k_begin = 0; sp.k_end = L.K;
-    TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, sp);
+    sp.W = tg_csr(m, 4); sp.A = a.X; sp.Y = m->fp(L.o_acY); sp.E = m->fp(L.o_acD); sp.V = L.Vs; sp.Kp = L.Kp; sp.k_begin = 0; sp.k_end = L.K;
+    TG_LAUNCH(tg_spmm, L.Vs, 1, 256, 0, m->stream, sp);
     TG_LAUNCH(tg_ac_stats1, nrb, 1, 256, 0, m->stream, a);
     TG_LAUNCH(tg_stat_reduce, kb, 1, 256, 0, m->stream, (const float*)a.part, nrb, (int)TGAC_NSTAT, L.Kp, a.stat);
     TG_LAUNCH(tg_ac_stats2, nrb, 1, 256, 0, m->stream, a);
@@ -494,17 +526,17 @@ static void tg_ac_indicators(tg_mapper* m, TgAcArgs& a) {
 
 static int tg_setup_autocorr(tg_mapper* m) {
     const TgLayout& L = m->L;
-    const int nrb = (L.V + TG_RB - 1) / TG_RB;
-    TG_LAUNCH(tg_csr_rowsum, (L.V + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 4), L.V, m->fp(L.o_acr), 0);
-    TG_LAUNCH(tg_csr_rowsum, (L.V + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 4), L.V, m->fp(L.o_acrc), 0);
-    TG_LAUNCH(tg_csr_rowsum, (L.V + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 5), L.V, m->fp(L.o_acrc), 1);
-    TgAcArgs a = tg_ac_args(m, m->fp(L.o_Gp), true, nullptr);       // indicators of G: the references (:144)
+    const int nrb = (L.Vs + TG_RB - 1) / TG_RB;
+    TG_LAUNCH(tg_csr_rowsum, (L.Vs + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 4), L.Vs, m->fp(L.o_acr), 0);
+    TG_LAUNCH(tg_csr_rowsum, (L.Vs + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 4), L.Vs, m->fp(L.o_acrc), 0);
+    TG_LAUNCH(tg_csr_rowsum, (L.Vs + 255) / 256, 1, 256, 0, m->stream, tg_csr(m, 5), L.Vs, m->fp(L.o_acrc), 1);
+    TgAcArgs a = tg_ac_args(m, tg_sp_g(m), true, nullptr);       // indicators of G: the references (:144)
     tg_ac_indicators(m, a);
     TG_LAUNCH(tg_ac_refs, nrb, 1, 256, 0, m->stream, a);
     // |Tg_k|^2 and |Tm_k|^2 (rows 0 and 2 of tnorm)
-    TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tg, (const float*)a.Tg, L.V, L.Kp, a.part);
+    TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tg, (const float*)a.Tg, L.Vs, L.Kp, a.part);
     TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm));
-    TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tm, (const float*)a.Tm, L.V, L.Kp, a.part);
+    TG_LAUNCH(tg_colstats, nrb, 1, 256, 0, m->stream, (const float*)a.Tm, (const float*)a.Tm, L.Vs, L.Kp, a.part);
     TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)a.part, nrb, L.Kp, m->fp(L.o_actnorm) + 2 * (size_t)L.Kp);
     TG_LAUNCH_CK();
     return TG_OK;
@@ -513,22 +545,22 @@ static int tg_setup_autocorr(tg_mapper* m) {
 // per iteration, after tg_loss_finalize (which starts the history row)
 static int tg_launch_autocorr(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
-    const int nrb = (L.V + TG_RB - 1) / TG_RB, kb = (L.Kp + 255) / 256;
-    TgAcArgs a = tg_ac_args(m, m->fp(L.o_Ghat), false, hist_row);
+    const int nrb = (L.Vs + TG_RB - 1) / TG_RB, kb = (L.Kp + 255) / 256;
+    TgAcArgs a = tg_ac_args(m, tg_sp_ghat(m), false, hist_row);
     tg_ac_indicators(m, a);
     if (a.lam_geary > 0.f) {
         TgSpmmArgs sz = {};
-        sz.W = tg_csr(m, 5); sz.A = a.X; sz.Y = m->fp(L.o_acZ); sz.V = L.V; sz.Kp = L.Kp; sz.k_begin = 0; sz.k_end = L.K;
-        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, sz);
+        sz.W = tg_csr(m, 5); sz.A = a.X; sz.Y = m->fp(L.o_acZ); sz.V = L.Vs; sz.Kp = L.Kp; sz.k_begin = 0; sz.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.Vs, 1, 256, 0, m->stream, sz);
     }
     TgAcFinArgs f; f.a = a; f.tnorm = m->fp(L.o_actnorm);
     TG_LAUNCH(tg_ac_finalize, 1, 1, 1024, 64, m->stream, f);
     TG_LAUNCH(tg_ac_grad, nrb, 1, 256, 0, m->stream, a);
     TG_LAUNCH(tg_stat_reduce, kb, 1, 256, 0, m->stream, (const float*)a.cmpart, nrb, 1, L.Kp, a.cm);
     TgSpmmArgs sg = {};       // extra[:, :K] (+)= Ws^T B1 + D - cm
-    sg.W = tg_csr(m, 5); sg.A = a.B1; sg.Y = m->fp(L.o_extra); sg.V = L.V; sg.Kp = L.Kp; sg.k_begin = 0; sg.k_end = L.K;
+    sg.W = tg_csr(m, 5); sg.A = a.B1; sg.Y = m->fp(L.o_extra); sg.V = L.Vs; sg.Kp = L.Kp; sg.k_begin = 0; sg.k_end = L.K;
     sg.accumulate = L.has_nb ? 1 : 0; sg.addD = a.D; sg.addc = a.cm;
-    TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, sg);
+    TG_LAUNCH(tg_spmm, L.Vs, 1, 256, 0, m->stream, sg);
     tg_prof_mark(m, "tg_spatial_autocorr");
     return TG_OK;
 }
@@ -539,8 +571,8 @@ static int tg_launch_spatial_grad(tg_mapper* m) {
     if (L.has_nb) {
         TgSpmmArgs a = {};
         a.W = tg_csr(m, 1); a.A = m->fp(L.o_WG); a.B = m->fp(L.o_Y); a.ca = m->fp(L.o_nbcoef); a.cb = m->fp(L.o_nbcoef) + L.Kp;
-        a.Y = m->fp(L.o_extra); a.V = L.V; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
-        TG_LAUNCH(tg_spmm, L.V, 1, 256, 0, m->stream, a);
+        a.Y = m->fp(L.o_extra); a.V = L.Vs; a.Kp = L.Kp; a.k_begin = 0; a.k_end = L.K;
+        TG_LAUNCH(tg_spmm, L.Vs, 1, 256, 0, m->stream, a);
         tg_prof_mark(m, "tg_spatial_nb_grad");
     }
     return TG_OK;
@@ -617,7 +649,10 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
               (const float*)(m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp), L.nrb, L.Kp, m->fp(L.o_gfrac), 1.f / (float)L.V);
     if (cfg->has_density) TG_LAUNCH(tg_vec_sum, 1, 1, 1024, 64, m->stream, (const float*)m->fp(L.o_d), L.V, m->fp(L.o_gnorm2) + L.Kp);
     if ((L.has_nb || L.has_ct || L.has_ac) && (rc = tg_setup_spatial(m, in))) return bail(rc);
-    if (L.has_ac && (rc = tg_setup_autocorr(m))) return bail(rc);
+    if (!L.sp_shard) {                      // (a spot shard derives these at tg_mapper_attach_comm, from the gathered G)
+        if ((L.has_nb || L.has_ct || L.has_ac) && (rc = tg_setup_spatial_derived(m))) return bail(rc);
+        if (L.has_ac && (rc = tg_setup_autocorr(m))) return bail(rc);
+    }
     // padding of the softmax statistics: shift = +3e38, scale = 0  => exp(M - shift) * scale == 0
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rshift), (size_t)L.Cp, 3.0e38f);
     TG_LAUNCH(tg_fill, (L.Cp + 255) / 256, 1, 256, 0, m->stream, m->fp(L.o_rscale), (size_t)L.Cp, 3.0e38f);
@@ -729,12 +764,13 @@ static void tg_loss_args(tg_mapper* m, float* hist_row, TgFinalizeArgs& f, TgEmi
     f.K = L.K; f.Kp = L.Kp; f.V = L.V; f.Vr = L.Vr; f.V_total = L.Vtot; f.has_density = m->cfg.has_density;
     f.nbstat = L.has_nb ? m->fp(L.o_nbstat) : nullptr; f.wgnorm2 = L.has_nb ? m->fp(L.o_wgn2) : nullptr;
     f.nbcoef = L.has_nb ? m->fp(L.o_nbcoef) : nullptr;
-    f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.V;
+    f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.Vs; f.V_sp = L.Vs;
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
     f.part_out = m->comm ? m->fp(L.o_rowpair) + 2 * (size_t)L.C : nullptr;       // spot shard: this rank's parts of the spot sums
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
-    e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) : nullptr;
+    // (spot shard: the extra gradient is evaluated for ALL spots; this handle's rows start at its spot offset)
+    e.extra = (L.has_nb || L.has_ct || L.has_ac) ? m->fp(L.o_extra) + (L.sp_shard ? (size_t)m->cfg.spot_offset * L.Kp : 0) : nullptr;
     e.V = L.V; e.Vr = L.Vr; e.Kp = L.Kp; e.K = L.K; e.n_aug = 1 + L.T_ct;
     e.fin = f;
 }
@@ -1271,9 +1307,19 @@ extern "C" int tg_mapper_attach_comm(tg_mapper* m, tg_comm* comm) {
     if (m->step != 0) return tg_fail(TG_ERR_STATE, "attach the communicator before the first step");
     if (comm->world > L.nranks) return tg_fail(TG_ERR_INVALID, "communicator of %d ranks but the handle was sized for n_ranks = %d", comm->world, L.nranks);
     if (!L.o_gathered) return tg_fail(TG_ERR_INVALID, "the handle was not created as a spot shard (n_ranks / n_spots_total)");
-    if (L.has_nb || L.has_ct || L.has_ac) return tg_fail(TG_ERR_UNSUPPORTED, "spatial terms need the whole spot graph on one GPU");
     if (L.bands > 1) return tg_fail(TG_ERR_UNSUPPORTED, "the cell-band pipeline is a single-GPU schedule");
+    if (L.sp_shard && (comm->world != L.nranks || m->cfg.spot_offset != comm->rank * L.Vmaxl))
+        return tg_fail(TG_ERR_INVALID, "spatial terms on spot shards: rank %d of %d must hold the spots from %d on (handle: %d ranks, offset %d)",
+                       comm->rank, comm->world, comm->rank * L.Vmaxl, L.nranks, m->cfg.spot_offset);
     m->comm = comm;
+    if (L.sp_shard) {
+        // the spatial terms see the whole spot graph: gather the blocks of G once (the references W G, |W G_k|^2 and the autocorrelation
+        // indicators of G are constants of the run), like Ghat every iteration
+        int rcs = tg_comm_all_gather(m, m->fp(L.o_Gp), m->fp(L.o_Gfull), (size_t)L.Vmaxl * L.Kp);
+        if (rcs) return rcs;
+        if ((rcs = tg_setup_spatial_derived(m))) return rcs;
+        if (L.has_ac && (rcs = tg_setup_autocorr(m))) return rcs;
+    }
     // set-up exchange: |G_k|^2 over all spots and the total of the density prior, then the softmax statistics of the initial logits
     int rc = tg_comm_all_reduce(m, m->fp(L.o_gnorm2), (size_t)L.Kp + 1);
     if (rc) return rc;
@@ -1290,6 +1336,7 @@ static int tg_one_step_sharded(tg_mapper* m, float lr, float* hist_row) {
     if ((rc = tg_launch_forward<PR>(m))) return rc;
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     if ((rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
+    if (L.sp_shard && (rc = tg_comm_all_gather(m, m->fp(L.o_Ghat), m->fp(L.o_GhatFull), (size_t)L.Vmaxl * L.Kp))) return rc;   // spatial terms: all of Ghat
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;                                    // (coefficients; dGhat operand image)
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);                                                // X + row-dot partials of this rank's spots
     tg_prof_mark(m, "tg_bwd_kernel");

@@ -543,6 +543,8 @@ struct TgFinalizeArgs {
     float* nbcoef;             // [2][Kp] -> d(loss)/d(W Ghat) = nbcoef0 * WG + nbcoef1 * WGhat
     const float* ctpart; int n_ctpart;   // per-spot sums of relu(D) (ct islands), or null
     float lambda_nb, lambda_ct; int T;
+    int V_sp;                  // spots the spatial sums (ct islands) run over: V, or ALL spots on a spot shard (the spatial terms are
+                               // evaluated on the gathered Ghat there, identically on every rank)
     float* part_out;           // spot shards: [0] = this rank's part of the voxel score (sum_v cos / V_total), [1] = of the KL sum; or null
 };
 
@@ -662,7 +664,7 @@ TG_DEV void tg_loss_scalars(const TgFinalizeArgs& a, float* red) {
     float sums[5] = {cs, nbs, cts, vs, kl};           // the five scalars share one block reduction
     tg_block_sums(sums, red);
     const float gv = sums[0] / (float)a.K, nbv = sums[1] / (float)a.K;
-    const float isl = sums[2] / ((float)a.V * (float)(a.T > 0 ? a.T : 1));
+    const float isl = sums[2] / ((float)a.V_sp * (float)(a.T > 0 ? a.T : 1));
     const float vg = sums[3] / (float)a.V_total, klsum = sums[4];
     if (t == 0) {
         const float nanv = __builtin_nanf("");

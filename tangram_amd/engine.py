@@ -95,21 +95,21 @@ class HipMapperEngine:
         if lam["lambda_neighborhood_g1"] > 0:
             if voxel_weights is None:
                 raise ValueError("lambda_neighborhood_g1 > 0 needs voxel_weights")
-            w, wt, cfg.nnz_w = _csr_pair(voxel_weights, self.V, self.device)
+            w, wt, cfg.nnz_w = _csr_pair(voxel_weights, cfg.n_spots_total, self.device)
             keep += [w, wt]
             inp.w_indptr, inp.w_indices, inp.w_data = (x.data_ptr() for x in w)
             inp.wt_indptr, inp.wt_indices, inp.wt_data = (x.data_ptr() for x in wt)
         if lam["lambda_getis_ord"] > 0 or lam["lambda_moran"] > 0 or lam["lambda_geary"] > 0:
             if spatial_weights is None:
                 raise ValueError("lambda_getis_ord / lambda_moran / lambda_geary > 0 need spatial_weights")
-            ws, wst, cfg.nnz_s = _csr_pair(spatial_weights, self.V, self.device)
+            ws, wst, cfg.nnz_s = _csr_pair(spatial_weights, cfg.n_spots_total, self.device)
             keep += [ws, wst]
             inp.s_indptr, inp.s_indices, inp.s_data = (x.data_ptr() for x in ws)
             inp.st_indptr, inp.st_indices, inp.st_data = (x.data_ptr() for x in wst)
         if lam["lambda_ct_islands"] > 0:
             if neighborhood_filter is None or ct_encode is None:
                 raise ValueError("lambda_ct_islands > 0 needs neighborhood_filter and ct_encode")
-            nn, nt, cfg.nnz_n = _csr_pair(neighborhood_filter, self.V, self.device)
+            nn, nt, cfg.nnz_n = _csr_pair(neighborhood_filter, cfg.n_spots_total, self.device)
             E = _as_dev_f32(ct_encode, self.device)
             if E.shape[0] != self.C:
                 raise ValueError("ct_encode must have one row per cell")

@@ -60,7 +60,7 @@ def _to_numpy_f32(x):
     return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
 
 
-def _shard_context(distributed, group, blockers):
+def _shard_context(distributed, group):
     """(sharded?, world, rank).  Sharding is opt-in: `distributed=True` shards the spots over the process group (which must
     be initialised); None / False keep the mapper on its own GPU even when a process group exists (the caller may be using
     it for independent per-rank work)."""
@@ -74,9 +74,6 @@ def _shard_context(distributed, group, blockers):
         raise RuntimeError("distributed=True needs an initialised torch.distributed process group (one rank per GPU)")
     if world <= 1:
         return False, world, rank
-    if blockers:
-        raise NotImplementedError("spot sharding is not available with " + ", ".join(blockers) +
-                                  " (the spatial terms need the whole spot graph on one GPU)")
     return True, world, rank
 
 
@@ -179,10 +176,7 @@ class Mapper:
                        lambda_r=lambda_r, lambda_l1=lambda_l1, lambda_l2=lambda_l2,
                        lambda_neighborhood_g1=lambda_neighborhood_g1, lambda_ct_islands=lambda_ct_islands,
                        lambda_getis_ord=lambda_getis_ord, lambda_moran=lambda_moran, lambda_geary=lambda_geary)
-        blockers = [n for n, on in (("lambda_neighborhood_g1", lambda_neighborhood_g1), ("lambda_ct_islands", lambda_ct_islands),
-                                    ("lambda_getis_ord", lambda_getis_ord), ("lambda_moran", lambda_moran),
-                                    ("lambda_geary", lambda_geary)) if on]
-        sharded, self._world, self._rank = _shard_context(distributed, group, blockers)
+        sharded, self._world, self._rank = _shard_context(distributed, group)
         if sharded:
             _check_same_problem(group, self.device, [S_train.shape[0], S_train.shape[1], G_train.shape[0], 0,
                                                      d is not None, d_source is not None] + [bool(v) for v in lambdas.values()])
@@ -197,7 +191,9 @@ class Mapper:
         if sharded:
             from .sharded import make_sharded
             self._sharded = make_sharded(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
-                                         device=self.device, precision=gemm_precision, lambdas=lambdas, group=group)
+                                         device=self.device, precision=gemm_precision, lambdas=lambdas, group=group,
+                                         voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
+                                         ct_encode=_to_numpy_f32(ct_encode), spatial_weights=spatial_weights)
             self._engine = self._sharded.eng
         else:
             self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
@@ -313,7 +309,7 @@ class MapperConstrained:
         self.target_count = G.shape[0] if target_count is None else target_count          # :480-483
         lambdas = dict(lambda_g1=lambda_g1, lambda_d=lambda_d if d is not None else 0.0, lambda_g2=lambda_g2,
                        lambda_r=lambda_r, lambda_count=lambda_count, lambda_f_reg=lambda_f_reg)
-        sharded, self._world, self._rank = _shard_context(distributed, group, [])
+        sharded, self._world, self._rank = _shard_context(distributed, group)
         if sharded:
             _check_same_problem(group, self.device, [S.shape[0], S.shape[1], G.shape[0], 1, d is not None, 0] +
                                 [bool(v) for v in lambdas.values()])

@@ -52,8 +52,13 @@ class DistComm:
         dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
 
 
-def shard_bounds(n, world, rank):
-    """Contiguous, balanced partition of range(n) into `world` blocks."""
+def shard_bounds(n, world, rank, blocks=False):
+    """Contiguous partition of range(n) into `world` blocks.  Default: balanced (the first n % world blocks one longer).
+    `blocks=True`: every block ceil(n / world) long, only the last shorter -- the partition of runs with spatial terms, whose
+    all-gathered blocks must BE the global spot-by-gene matrix (padding only at its end)."""
+    if blocks:
+        size = -(-n // world)
+        return min(rank * size, n), min((rank + 1) * size, n)
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
@@ -70,7 +75,7 @@ def rccl_library_path():
 class ShardedMapperEngine:
     def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, F0=None, *, n_spots_total, device, mode="mapper",
                  precision="bf16x3", lambdas=None, target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None,
-                 transport="auto", spot_offset=0):
+                 transport="auto", spot_offset=0, voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
         # `comm`: anything with world, rank, all_reduce, all_gather_into_tensor, all_gather (tests drive several shards of one
         # GPU through an in-process communicator); default: the torch.distributed group
         self.pycomm = comm if comm is not None else DistComm(group)
@@ -79,6 +84,10 @@ class ShardedMapperEngine:
         self.rank = self.pycomm.rank
         self.lam = dict(lambda_g1=1.0, lambda_d=0.0, lambda_g2=0.0, lambda_r=0.0, lambda_l1=0.0, lambda_l2=0.0)
         self.lam.update(lambdas or {})
+        # spatial terms (spot graphs over ALL spots, replicated on every rank): the library gathers Ghat every iteration and evaluates
+        # them on the whole graph, identically on every rank; the shards must then be the blocks of shard_bounds(..., blocks=True)
+        self.spatial = any(self.lam.get(k, 0) > 0 for k in ("lambda_neighborhood_g1", "lambda_ct_islands", "lambda_getis_ord",
+                                                             "lambda_moran", "lambda_geary"))
         self.mode = mode
         if F0 is not None and self.world > 1:
             # the filter logits are REPLICATED: every rank must start from rank 0's values (a caller that draws F0 per rank from
@@ -87,7 +96,8 @@ class ShardedMapperEngine:
         self.eng = HipMapperEngine(S, G_local, M0_local, d=d_local, d_source=d_source, F0=F0, mode=mode, device=device,
                                    precision=precision, lambdas=self.lam, n_spots_total=n_spots_total, n_ranks=self.world,
                                    fwd_splits=fwd_splits, tile_size=tile_size, bwd_tile=bwd_tile, target_count=target_count,
-                                   spot_offset=spot_offset)
+                                   spot_offset=spot_offset, voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
+                                   ct_encode=ct_encode, spatial_weights=spatial_weights)
         self.has_density = d_local is not None
         self.n_spots_total = int(n_spots_total)
         lib = self.eng._lib
@@ -193,7 +203,7 @@ class ShardedMapperEngine:
         return (P, F) if with_filter else P
 
     def _gather_columns_host(self, X_local):
-        bounds = [shard_bounds(self.n_spots_total, self.world, r) for r in range(self.world)]
+        bounds = [shard_bounds(self.n_spots_total, self.world, r, self.spatial) for r in range(self.world)]
         if not hasattr(self.pycomm, "broadcast"):
             return self._gather_columns(X_local).detach().cpu().numpy()
         out = np.empty((X_local.shape[0], self.n_spots_total), dtype=np.float32)
@@ -216,7 +226,7 @@ class ShardedMapperEngine:
         return self._gather_columns(Gh.t().contiguous()).t().contiguous()
 
     def _gather_columns(self, X_local):
-        widths = [b - a for a, b in (shard_bounds(self.n_spots_total, self.world, r) for r in range(self.world))]
+        widths = [b - a for a, b in (shard_bounds(self.n_spots_total, self.world, r, self.spatial) for r in range(self.world))]
         wmax = max(widths)
         pad = torch.zeros((X_local.shape[0], wmax), dtype=torch.float32, device=X_local.device)
         pad[:, :X_local.shape[1]] = X_local
@@ -239,12 +249,16 @@ class ShardedMapperEngine:
 
 
 def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapper", precision="bf16x3", lambdas=None,
-                 target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None, transport="auto"):
-    """Slice full problem arrays (identical on every rank) into this rank's spot block."""
+                 target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None, transport="auto",
+                 voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
+    """Slice full problem arrays (identical on every rank) into this rank's spot block.  The spot graphs of the spatial terms
+    (`voxel_weights`, `neighborhood_filter`, `spatial_weights`: V x V over ALL spots) and `ct_encode` are passed whole."""
     pc = comm if comm is not None else DistComm(group)
     world, rank = pc.world, pc.rank
     V = G.shape[0]
-    lo, hi = shard_bounds(V, world, rank)
+    lam = lambdas or {}
+    spatial = any(lam.get(k, 0) > 0 for k in ("lambda_neighborhood_g1", "lambda_ct_islands", "lambda_getis_ord", "lambda_moran", "lambda_geary"))
+    lo, hi = shard_bounds(V, world, rank, spatial)
     if hi - lo < 1:
         raise ValueError(f"rank {rank} would own no spots (V={V}, world={world})")
     G_l = G[lo:hi]
@@ -256,4 +270,5 @@ def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapp
     d_l = None if d is None else d[lo:hi]
     return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, F0, n_spots_total=V, device=device, mode=mode, precision=precision,
                                lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, tile_size=tile_size,
-                               bwd_tile=bwd_tile, comm=comm, transport=transport, spot_offset=lo)
+                               bwd_tile=bwd_tile, comm=comm, transport=transport, spot_offset=lo, voxel_weights=voxel_weights,
+                               neighborhood_filter=neighborhood_filter, ct_encode=ct_encode, spatial_weights=spatial_weights)

@@ -395,6 +395,52 @@ def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_spatial_terms_on_spot_shards_match_single_engine(world):
+    """Neighbourhood, cell-type-island and autocorrelation terms on spot shards (the library gathers Ghat every iteration and every
+    rank evaluates the terms on the whole spot graph, mapping_optimizer.py:234-263): shards as threads of one GPU (ceil partition,
+    last block shorter) against the unsharded engine and the fp64 oracle."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.sharded import make_sharded
+    from tangram_amd.synthetic import hex_grid_graph
+    from tangram_amd import _capi
+    from tests.local_comm import run_ranks
+    C, K, V, T, n = 500, 40, 1001, 5, 5
+    data = orc.make_synthetic(C, K, V, seed=19, n_types=T)
+    M0 = orc.reference_init_M(C, V, 2)
+    N, W = hex_grid_graph(V)
+    Ws = orc.grid_graph(V, standardized=True, self_inclusion=False)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.3, lambda_neighborhood_g1=0.96, lambda_ct_islands=0.17,
+               lambda_getis_ord=0.4, lambda_moran=0.3, lambda_geary=0.2)
+    graphs = dict(voxel_weights=W, neighborhood_filter=N, ct_encode=data["ct_encode"], spatial_weights=Ws)
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, comm=comm, **graphs)
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist)
+        out = hist.cpu().numpy(), sh.result_full().cpu().numpy()
+        sh.release()
+        return out
+
+    res = run_ranks(world, rank_fn)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, **graphs)
+    h1 = e.new_history(n)
+    e.step(n, 0.1, h1)
+    h1, P1 = h1.cpu().numpy(), e.result().cpu().numpy()
+    e.release()
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, voxel_weights=W.toarray(),
+                         neighborhood_filter=N.toarray(), ct_encode=data["ct_encode"], spatial_weights=Ws, **lam)
+    Po, ho = o.train(n, 0.1)
+    cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_NB, _capi.H_CT, _capi.H_GETIS, _capi.H_MORAN, _capi.H_GEARY]
+    for hist, P in res:
+        np.testing.assert_array_equal(hist, res[0][0])                         # the same global history on every rank
+        np.testing.assert_allclose(hist[:, cols], h1[:, cols], atol=5e-6, rtol=2e-6)
+        np.testing.assert_allclose(P, P1, atol=2e-6)
+        np.testing.assert_allclose(hist[:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
+        assert np.abs(P - Po).max() < 2e-4
+
+
+@pytest.mark.parametrize("world", [2, 3])
 def test_constrained_spot_shards_match_single_engine(world):
     """MapperConstrained on spot shards (the filter F is replicated; its gradient comes from the all-reduced row sums, the
     density prior's total from the set-up exchange): same history, mapping, filter and projection as the unsharded engine

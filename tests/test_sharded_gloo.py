@@ -217,3 +217,81 @@ def test_map_cells_to_space_shards_over_the_process_group(tmp_path):
             assert np.isfinite(z0[f"unseeded_{rs}_loss"]).all()
     finally:
         _capi._install_library_for_tests(None)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# spatial terms on spot shards: every rank gathers Ghat and evaluates the terms on the whole spot graph
+# ------------------------------------------------------------------------------------------------------------------------
+SP_SHAPE = (60, 18, 131)           # 131 spots over 2 ranks: blocks of 66 and 65 (ceil partition)
+SP_LAM = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.4, lambda_neighborhood_g1=0.8, lambda_ct_islands=0.3,
+              lambda_getis_ord=0.5, lambda_moran=0.4, lambda_geary=0.3)
+
+
+def _spatial_problem():
+    from oracle import tangram_oracle as orc
+    C, K, V = SP_SHAPE
+    data = orc.make_synthetic(C, K, V, seed=12, n_types=4)
+    M0 = orc.reference_init_M(C, V, 3)
+    W = orc.grid_graph(V, standardized=True, self_inclusion=True)          # voxel_weights (mapping_utils.py:320)
+    N = orc.grid_graph(V, standardized=False, self_inclusion=False)        # neighborhood_filter (:324)
+    Ws = orc.grid_graph(V, standardized=True, self_inclusion=False)        # spatial_weights (:326-329)
+    return data, M0, dict(voxel_weights=W, neighborhood_filter=N, ct_encode=data["ct_encode"], spatial_weights=Ws)
+
+
+def _spatial_worker(rank, world, port, sim_path, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tangram_amd import _capi
+        _capi._install_library_for_tests(sim_path)
+        from tangram_amd.sharded import make_sharded
+        import tangram_amd.mapping_optimizer as mo
+        data, M0, graphs = _spatial_problem()
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=SP_LAM, **graphs)
+        n = 4
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist)
+        P = sh.result_full()
+        # the same through the Mapper seam (distributed=True): history keys of the reference + the mapping
+        m = mo.Mapper(S=data["S"], G=data["G"], d=data["d"], device="cpu", gemm_precision="fp32", M_init=M0, distributed=True,
+                      **{k: v for k, v in SP_LAM.items()}, **graphs)
+        Pm, hm = m.train(num_epochs=n, print_each=None)
+        np.savez(os.path.join(outdir, f"spatial_{rank}.npz"), P=P.numpy(), hist=hist.numpy(), Pm=Pm,
+                 total=np.array([float(x) for x in hm["total_loss"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spatial_terms_on_two_shards_match_single_and_oracle(tmp_path):
+    """Neighbourhood, cell-type-island and the three autocorrelation terms on 2 spot shards (mapping_optimizer.py:234-263 on the
+    whole spot graph: every rank gathers Ghat): same history and mapping as the unsharded engine and the fp64 oracle."""
+    sim_path = build_sim()
+    if sim_path is None:
+        pytest.skip("host clang not available to build the emulator")
+    mp.spawn(_spatial_worker, args=(2, _free_port(), sim_path, str(tmp_path)), nprocs=2, join=True)
+    z0, z1 = np.load(tmp_path / "spatial_0.npz"), np.load(tmp_path / "spatial_1.npz")
+    for k in z0.files:
+        np.testing.assert_array_equal(z0[k], z1[k], err_msg=k)
+    from tangram_amd import _capi
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    data, M0, graphs = _spatial_problem()
+    n = 4
+    _capi._install_library_for_tests(sim_path)
+    try:
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=SP_LAM, **graphs)
+        h1 = e.new_history(n)
+        e.step(n, 0.1, h1)
+        P1 = e.result().numpy()
+    finally:
+        _capi._install_library_for_tests(None)
+    cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_NB, _capi.H_CT, _capi.H_GETIS, _capi.H_MORAN, _capi.H_GEARY]
+    np.testing.assert_allclose(z0["hist"][:, cols], h1.numpy()[:, cols], atol=3e-6, rtol=2e-6)
+    np.testing.assert_allclose(z0["P"], P1, atol=2e-6)
+    np.testing.assert_allclose(z0["Pm"], P1, atol=2e-6)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **SP_LAM, **graphs)
+    Po, ho = o.train(n, 0.1)
+    np.testing.assert_allclose(z0["hist"][:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(z0["total"], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
+    assert np.abs(z0["P"] - Po).max() < 2e-5
