@@ -190,7 +190,7 @@ int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_de
  * of ONE shape / configuration together: every kernel of the iteration is launched once with blockIdx.z = mapping (its arguments
  * come from arrays in `scratch_dev`, tg_batch_query_bytes(B) bytes of device memory).  The handles stay usable on their own
  * (result, project, state); they must share the stream they were created on and stay at the same step.  Results are the bits of
- * stepping each handle alone.  Mapper mode without spatial terms, rows <= 16 384 spots.
+ * stepping each handle alone.  Handles of ONE class (all Mapper or all MapperConstrained), without spatial terms, rows <= 16 384 spots.
  * history_dev: host array of B device pointers (one history buffer per mapping) or NULL.                                        */
 typedef struct tg_batch tg_batch;
 size_t tg_batch_query_bytes(int n_mappers);

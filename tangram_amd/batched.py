@@ -9,7 +9,8 @@ Clusters-mode problems are tiny (18 x 250 x 9852) and launch-bound on a 256-CU G
 `MapperBatch` / `train_many` advance B mappings of one shape in ONE launch per kernel: the C library's `tg_batch` puts the
 per-mapping kernel arguments into device arrays and adds a batch index to the grid of every kernel of the iteration
 (blockIdx.z = mapping).  Results are the bits of training the same mappings one by one: nothing is shared between them.
-Mappings that cannot be batched (a shape of their own, MapperConstrained, spatial terms, more than 16 384 spots, `val_each`, or
+`Mapper`s batch with `Mapper`s, `MapperConstrained`s with `MapperConstrained`s (utils.py:576-600 passes any `mode`).
+Mappings that cannot be batched (a shape of their own, spatial terms, more than 16 384 spots, `val_each`, or
 a group the C library refuses) are trained by one host thread per mapping (the C ABI releases the GIL; different handles may be
 driven from different threads); `batched=False` additionally gives every mapping a HIP stream of its own.
 """
@@ -24,7 +25,7 @@ from . import _capi
 
 
 class MapperBatch:
-    """B `Mapper`s of one shape / configuration stepped together (tg_batch)."""
+    """B `Mapper`s -- or B `MapperConstrained`s -- of one shape / configuration stepped together (tg_batch)."""
 
     def __init__(self, mappers):
         self.mappers = list(mappers)
@@ -71,7 +72,7 @@ def _batch_key(m):
     """Mappings with equal keys can share a tg_batch: the limits of tg_batch_create (tg_capi.hip) are applied here, so that a
     group the C library would refuse is never formed (the C library re-checks; a refusal falls back to the stream path)."""
     e = getattr(m, "_engine", None)
-    if type(m).__name__ != "Mapper" or e is None or getattr(m, "_sharded", None) is not None:
+    if type(m).__name__ not in ("Mapper", "MapperConstrained") or e is None or getattr(m, "_sharded", None) is not None:
         return None
     c = e.cfg
     if c.lambda_neighborhood_g1 or c.lambda_ct_islands or c.lambda_getis_ord or c.lambda_moran or c.lambda_geary:
@@ -79,7 +80,7 @@ def _batch_key(m):
     if e.V > ROWPASS_MAX_SPOTS or e.K + 1 + 256 > EMIT_MAX_GENE_COLS or c.pipeline_bands > 1:
         return None
     stream = e._torch_stream.cuda_stream if e._torch_stream is not None else 0
-    return (e.C, e.K, e.V, e.precision, bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device), stream,
+    return (type(m).__name__, e.C, e.K, e.V, e.precision, bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device), stream,
             c.beta1, c.beta2, c.tile_size, c.fwd_splits)
 
 
@@ -89,8 +90,11 @@ def _train_batched(mappers, num_epochs, learning_rate):
     batch.step(int(num_epochs), learning_rate, hists, 0)
     out = []
     for m, h in zip(mappers, hists):
-        P = m._engine.result().detach().cpu().numpy()
-        out.append((P, m._history_dict(h[:num_epochs])))
+        if type(m).__name__ == "MapperConstrained":            # train() -> (mapping, filter, history) (mapping_utils.py:387-389)
+            P, F = m._engine.result(with_filter=True)
+            out.append((P.detach().cpu().numpy(), F.detach().cpu().numpy(), m._history_dict(h[:num_epochs])))
+        else:
+            out.append((m._engine.result().detach().cpu().numpy(), m._history_dict(h[:num_epochs])))
     batch.close()
     return out
 
@@ -101,7 +105,7 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
     builders: callables, each returning a `Mapper` / `MapperConstrained`.  They are called one after the other on the
               calling thread (the reference's initialisation draws from the global NumPy RNG, `np.random.seed(random_state)`,
               which must not be interleaved).
-    batched:  "auto" (default): mappings that can share a `tg_batch` (Mapper, one shape, no spatial terms, <= 16 384 spots, no
+    batched:  "auto" (default): mappings that can share a `tg_batch` (one class, one shape, no spatial terms, <= 16 384 spots, no
               `val_each`) advance in ONE launch per kernel; the others -- and any group the C library refuses -- get a host
               thread each, their kernels sharing the common creation stream.  False: every mapper is created on a HIP stream
               of its own and trained by its own host thread (`max_concurrent` at a time): kernels of different mappings overlap.

@@ -404,8 +404,7 @@ static int tg_softmax_stats_from_scratch(tg_mapper* m) {
     return TG_OK;
 }
 
-static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize, bool want_pair, float* global_hist_row = nullptr,
-                    int rank = 0) {
+static TgMergeArgs tg_merge_args(tg_mapper* m, const float* parts, int nparts, bool finalize, bool want_pair, float* global_hist_row, int rank) {
     const TgLayout& L = m->L;
     TgMergeArgs a;
     a.part = parts; a.nparts = nparts; a.C = L.C; a.stride = L.pair_stride;
@@ -416,6 +415,12 @@ static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize,
     a.fgate = (m->cfg.mode == TG_MODE_CONSTRAINED) ? m->fp(L.o_fgate) : nullptr;
     a.hist = global_hist_row; a.rank = rank;
     a.lambda_g2 = m->cfg.lambda_g2; a.lambda_d = m->cfg.lambda_d; a.has_density = m->cfg.has_density;
+    return a;
+}
+static int tg_merge(tg_mapper* m, const float* parts, int nparts, bool finalize, bool want_pair, float* global_hist_row = nullptr,
+                    int rank = 0) {
+    const TgLayout& L = m->L;
+    const TgMergeArgs a = tg_merge_args(m, parts, nparts, finalize, want_pair, global_hist_row, rank);
     TG_LAUNCH(tg_merge_stats, (L.C + 255) / 256, 1, 256, 0, m->stream, a);
     tg_prof_mark(m, "tg_merge_stats");
     TG_LAUNCH_CK();
@@ -578,7 +583,7 @@ static int tg_launch_spatial_grad(tg_mapper* m) {
     return TG_OK;
 }
 
-static int tg_launch_filter(tg_mapper* m, bool update, float lr, float* hist_row) {
+static TgFilterArgs tg_filter_args(tg_mapper* m, bool update, float lr, float* hist_row) {
     const TgLayout& L = m->L;
     TgFilterArgs a;
     float* F = (float*)(m->st + L.s_F);
@@ -592,6 +597,10 @@ static int tg_launch_filter(tg_mapper* m, bool update, float lr, float* hist_row
     a.step_size = (float)((double)lr / (1.0 - pow((double)m->cfg.beta1, t)));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
     a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
+    return a;
+}
+static int tg_launch_filter(tg_mapper* m, bool update, float lr, float* hist_row) {
+    const TgFilterArgs a = tg_filter_args(m, update, lr, hist_row);
     TG_LAUNCH(tg_filter_kernel, 1, 1, 1024, 64, m->stream, a);
     tg_prof_mark(m, "tg_filter_kernel");
     return TG_OK;
@@ -1033,7 +1042,7 @@ static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool f
 struct tg_batch {
     std::vector<tg_mapper*> h;
     unsigned char* dev;                              // caller-provided scratch: the argument arrays
-    size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, total;
+    size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, o_filt, o_merge, o_scr, total;
     std::vector<float*> hist;                        // history base pointers the argument arrays currently hold
     bool args_valid;
 };
@@ -1042,8 +1051,10 @@ static size_t tg_batch_layout(int n, tg_batch* b) {
     auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
     const size_t o_fwd = take(n * sizeof(TgFwdArgs)), o_ghat = take(n * sizeof(TgGhatReduceArgs)), o_gene = take(n * sizeof(TgGeneReduceArgs)),
                  o_emit = take(n * sizeof(TgEmitArgs)), o_bwd = take(n * sizeof(TgBwdArgs)), o_upd = take(n * sizeof(TgUpdateArgs)),
-                 o_hreg = take(n * sizeof(TgHistRegArgs));
-    if (b) { b->o_fwd = o_fwd; b->o_ghat = o_ghat; b->o_gene = o_gene; b->o_emit = o_emit; b->o_bwd = o_bwd; b->o_upd = o_upd; b->o_hreg = o_hreg; b->total = off; }
+                 o_hreg = take(n * sizeof(TgHistRegArgs)), o_filt = take(n * sizeof(TgFilterArgs)), o_merge = take(n * sizeof(TgMergeArgs)),
+                 o_scr = take(n * sizeof(float*));
+    if (b) { b->o_fwd = o_fwd; b->o_ghat = o_ghat; b->o_gene = o_gene; b->o_emit = o_emit; b->o_bwd = o_bwd; b->o_upd = o_upd; b->o_hreg = o_hreg;
+             b->o_filt = o_filt; b->o_merge = o_merge; b->o_scr = o_scr; b->total = off; }
     return off;
 }
 extern "C" size_t tg_batch_query_bytes(int n_mappers) { return n_mappers > 0 ? tg_batch_layout(n_mappers, nullptr) : 0; }
@@ -1059,7 +1070,7 @@ extern "C" int tg_batch_create(tg_mapper* const* mappers, int n, void* scratch_d
             return tg_fail(TG_ERR_INVALID, "mapper %d differs in shape / precision / terms from mapper 0 (a batch is B mappings of ONE shape)", i);
         if (m->stream != m0->stream) return tg_fail(TG_ERR_INVALID, "all mappers of a batch must be created on the same stream");
         if (m->step != m0->step) return tg_fail(TG_ERR_INVALID, "all mappers of a batch must be at the same step");
-        if (m->cfg.mode != TG_MODE_MAPPER) return tg_fail(TG_ERR_UNSUPPORTED, "batches hold Mapper handles (MapperConstrained: use streams)");
+        if (m->cfg.mode != m0->cfg.mode) return tg_fail(TG_ERR_INVALID, "a batch holds handles of ONE class (Mapper or MapperConstrained)");
         if (m->comm || A.Vtot != A.V || A.bands > 1 || !tg_emit_self_ok(m) || A.V > TG_ROWPASS_MAX_V)
             return tg_fail(TG_ERR_UNSUPPORTED, "mapper %d uses spatial terms, spot shards, the band pipeline or rows longer than %d spots", i, TG_ROWPASS_MAX_V);
         if (m->cfg.beta1 != m0->cfg.beta1 || m->cfg.beta2 != m0->cfg.beta2) return tg_fail(TG_ERR_INVALID, "Adam betas differ inside the batch");
@@ -1081,6 +1092,8 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
     const int n = (int)b->h.size();
     std::vector<TgFwdArgs> fw(n); std::vector<TgGhatReduceArgs> gh(n); std::vector<TgGeneReduceArgs> gr(n);
     std::vector<TgEmitArgs> em(n); std::vector<TgBwdArgs> bw(n); std::vector<TgUpdateArgs> up(n); std::vector<TgHistRegArgs> hr(n);
+    std::vector<TgFilterArgs> fl(n); std::vector<TgMergeArgs> mg(n); std::vector<float*> scr(n);
+    const bool constrained = (b->h[0]->cfg.mode == TG_MODE_CONSTRAINED);
     for (int i = 0; i < n; ++i) {
         tg_mapper* m = b->h[i];
         const TgLayout& L = m->L;
@@ -1093,9 +1106,15 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
         f.hist = hist ? hist[i] : nullptr;                      // BASE of the mapping's history (row offset: TgStepVar)
         em[i].fin = f;
         bw[i] = tg_bwd_args<PR>(m, 0, L.nct, &grid);
-        up[i] = tg_update_args(m, 0.f, true, 0, L.C);
+        up[i] = tg_update_args(m, 0.f, !constrained, 0, L.C);       // (MapperConstrained: tg_merge_stats folds the NEW filter in afterwards)
         up[i].fin = f; up[i].fin_on = 1;
-        hr[i] = TgHistRegArgs{m->fp(L.o_rowq), L.C, hist ? hist[i] : nullptr, m->cfg.lambda_r, m->cfg.lambda_l1, m->cfg.lambda_l2, 0};
+        hr[i] = TgHistRegArgs{m->fp(L.o_rowq), L.C, hist ? hist[i] : nullptr, m->cfg.lambda_r, m->cfg.lambda_l1, m->cfg.lambda_l2, constrained ? 1 : 0};
+        if (constrained) {
+            fl[i] = tg_filter_args(m, true, 0.f, nullptr);
+            fl[i].hist = hist ? hist[i] : nullptr;               // BASE of the history (row offset: TgStepVar), like the update kernel's
+            mg[i] = tg_merge_args(m, m->fp(L.o_rowpair), 1, true, false, nullptr, 0);
+        }
+        scr[i] = m->fp(L.o_scal);
     }
     tg_stream_t s = b->h[0]->stream;
     TG_CK(tg_memcpy_h2d(b->dev + b->o_fwd, fw.data(), n * sizeof(TgFwdArgs), s));
@@ -1105,6 +1124,9 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
     TG_CK(tg_memcpy_h2d(b->dev + b->o_bwd, bw.data(), n * sizeof(TgBwdArgs), s));
     TG_CK(tg_memcpy_h2d(b->dev + b->o_upd, up.data(), n * sizeof(TgUpdateArgs), s));
     TG_CK(tg_memcpy_h2d(b->dev + b->o_hreg, hr.data(), n * sizeof(TgHistRegArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_filt, fl.data(), n * sizeof(TgFilterArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_merge, mg.data(), n * sizeof(TgMergeArgs), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_scr, scr.data(), n * sizeof(float*), s));
 #ifndef TG_SIM
     TG_CK(hipStreamSynchronize(s));        // (the host vectors go out of scope; once per tg_batch_step call, not per iteration)
 #endif
@@ -1167,6 +1189,10 @@ static int tg_batch_step_impl(tg_batch* b, int n_steps, float lr, float* const* 
         if (L.full) { if (x16) tg_launch_rowpass_b<true, true>(a_up, var, L.C + 1, L.V, n, s); else tg_launch_rowpass_b<true, false>(a_up, var, L.C + 1, L.V, n, s); }
         else { if (x16) tg_launch_rowpass_b<false, true>(a_up, var, L.C + 1, L.V, n, s); else tg_launch_rowpass_b<false, false>(a_up, var, L.C + 1, L.V, n, s); }
         if (L.full) TG_LAUNCH3(tg_hist_regs_b, 1, 1, n, 1024, 64, s, a_hr, var);
+        if (m0->cfg.mode == TG_MODE_CONSTRAINED) {      // Adam on the filters, then the new filters folded into the forward row constants
+            TG_LAUNCH3(tg_filter_kernel_b, 1, 1, n, 1024, 64, s, (const TgFilterArgs*)(b->dev + b->o_filt), var, (float* const*)(b->dev + b->o_scr));
+            TG_LAUNCH3(tg_merge_stats_b, (L.C + 255) / 256, 1, n, 256, 0, s, (const TgMergeArgs*)(b->dev + b->o_merge));
+        }
         for (int i = 0; i < n; ++i) b->h[i]->step += 1;
         if (tg_launch_failed()) return tg_launch_status();
     }

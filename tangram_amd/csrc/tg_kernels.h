@@ -48,6 +48,9 @@ template <bool STREAM, class T> TG_DEV void tg_st_stream(const T& v, T* p) {
 enum { TGH_TOTAL = 0, TGH_MAIN, TGH_VG, TGH_KL, TGH_ENTROPY, TGH_L1, TGH_L2, TGH_NB, TGH_CT, TGH_COUNT, TGH_FREG,
        TGH_GETIS, TGH_MORAN, TGH_GEARY, TGH_NTERMS = 16 };
 
+// what changes from step to step in a batch of mappings (tg_batch; everything else is constant per mapping and lives in argument arrays)
+struct TgStepVar { float step_size, bc2_sqrt; long long hist_row; };    // hist_row < 0: no history wanted
+
 // ----------------------------------------------------------------------------------------------
 // shared GEMM tile machinery.  Output tile TM x TN, 64*WM*WN threads, each wave owns (TM/WM) x (TN/WN)
 // = FM x FN MFMA 16x16 fragments.  One LDS stage = {A tile: TM rows, B tile: TN rows} of 128-byte rows
@@ -1554,7 +1557,6 @@ TG_DEV void tg_hist_regs_body(const TgHistRegArgs& a) {
 // ----------------------------------------------------------------------------------------------
 struct TgGeneReduceArgs { const float* genepart; int nrb, Kp; float* genestat; };
 // what changes from step to step in a batch (everything else is constant per mapping and lives in the argument arrays)
-struct TgStepVar { float step_size, bc2_sqrt; long long hist_row; };    // hist_row < 0: no history wanted
 
 template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel(TgFwdArgs a) { tg_fwd_body<PR, GE>(a); }
 template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd_kernel_b(const TgFwdArgs* argv) {
@@ -1609,7 +1611,7 @@ struct TgFilterArgs {
     float lambda_d, lambda_count, lambda_f_reg, target_count;
     float step_size, bc2_sqrt, beta1, beta2, eps;
 };
-TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel(TgFilterArgs a) {
+TG_DEV void tg_filter_body(const TgFilterArgs& a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;
     const int t = threadIdx.x;
@@ -1650,6 +1652,15 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel(TgFilterArgs a) {
     if (t == 0) a.fsum[0] = fsum_new;
 }
 
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel(TgFilterArgs a) { tg_filter_body(a); }
+// batched (tg_batch of MapperConstrained handles): Adam step constants and the history row travel by value
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_filter_kernel_b(const TgFilterArgs* argv, TgStepVar var, float* const* scratch_rows) {
+    TgFilterArgs a = argv[blockIdx.z];
+    a.step_size = var.step_size; a.bc2_sqrt = var.bc2_sqrt;
+    a.hist = (var.hist_row >= 0 && a.hist) ? a.hist + var.hist_row * TGH_NTERMS : scratch_rows[blockIdx.z];
+    tg_filter_body(a);
+}
+
 // merge (max, sum exp) partials over `nparts` -> rshift = max, rinvz = 1/Z ; optional raw output.
 // Spot shards (nparts = ranks, `part` = the all-gathered blocks of `stride` floats: [2][C] pairs + TG_PAIR_TAIL history
 // scalars): thread 0 of block 0 also turns this rank's history row into the GLOBAL one -- the terms that are sums over spots
@@ -1665,7 +1676,7 @@ struct TgMergeArgs {
     float* hist; int rank;     // spot shards: history row to complete with the global spot sums (or null), this rank's index
     float lambda_g2, lambda_d; int has_density;
 };
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
+TG_DEV void tg_merge_stats_body(const TgMergeArgs& a) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (a.hist && blockIdx.x == 0 && threadIdx.x == 0) {
         const float* tail = a.part + 2 * (size_t)a.C;
@@ -1705,6 +1716,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) {
         a.rscale[c] = (mx + tg_log(z) - (a.fgate ? tg_log(a.fgate[c]) : 0.f)) * TG_LOG2E;
     }
 }
+
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) { tg_merge_stats_body(a); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats_b(const TgMergeArgs* argv) { tg_merge_stats_body(argv[blockIdx.z]); }
 
 // forward row constant of the bf16 path WITHOUT the constrained-mode filter: (max + ln Z) * log2(e)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_plain_rscale(const float* rshift, const float* rinvz, int C, float* out) {

@@ -357,14 +357,18 @@ class MapperConstrained:
             P, F = (torch.as_tensor(x) for x in self._sharded.result_full(with_filter=True, host=True))
         else:
             P, F = eng.result(with_filter=True)
-        h = hist[:num_epochs].detach().cpu().numpy()
+        return P.detach().cpu().numpy(), F.detach().cpu().numpy(), self._history_dict(hist[:num_epochs])
+
+    def _history_dict(self, hist):
+        """History rows -> the reference's dict of stringified values (:609-617, :630)."""
+        h = hist.detach().cpu().numpy()
         cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY, _capi.H_COUNT, _capi.H_FREG]
         active = [True, True, bool(self.lambda_g2), bool(self.target_density_enabled and self.lambda_d), bool(self.lambda_r), True, True]
         history = {k: [] for k in _KEYS_CONSTRAINED}
         for row in h:
             for k, c, on in zip(_KEYS_CONSTRAINED, cols, active):
                 history[k].append(str(float(row[c]) if on else float("nan")))
-        return P.detach().cpu().numpy(), F.detach().cpu().numpy(), history
+        return history
 
     def release(self):
         """Free the device memory of this mapper; the object is unusable afterwards."""

@@ -53,6 +53,51 @@ def check_batched(device, precision, C, K, V, B, epochs, lam, tol_loss, tol_P):
     assert len({m._engine.logits()[3] for m in mappers}) == 1
 
 
+def check_batched_constrained(device, precision, C, K, V, B, epochs, tol_loss, tol_P):
+    """B MapperConstrained folds in one tg_batch (cross_val passes any `mode`, utils.py:576-600): every batch element bit-identical
+    to the same mapping trained alone, and against the fp64 oracle (mapping, filter, history incl. count / f_reg terms)."""
+    import tangram_amd as tg
+    import tangram_amd.mapping_optimizer as mo
+    from tangram_amd.batched import _batch_key
+    from oracle import tangram_oracle as orc
+    data = orc.make_synthetic(C, K, V, seed=4)
+    lam = dict(lambda_d=1, lambda_g1=1, lambda_g2=0.5, lambda_r=1e-3, lambda_count=0.8, lambda_f_reg=1.3)
+    tc = 0.3 * V
+
+    def fold(i):
+        keep = [g for g in range(K) if g != i]
+        return dict(S=data["S"][:, keep], G=data["G"][:, keep], d=data["d"], target_count=tc, **lam), i + 3
+
+    def builder(i):
+        kw, seed = fold(i)
+        return lambda: mo.MapperConstrained(device=device, random_state=seed, gemm_precision=precision, **kw)
+
+    res, mappers = tg.train_many([builder(i) for i in range(B)], epochs, 0.1, device=device)
+    assert len({_batch_key(m) for m in mappers}) == 1 and _batch_key(mappers[0]) is not None      # they DID share one tg_batch
+    solo = [builder(i)().train(num_epochs=epochs, learning_rate=0.1, print_each=None) for i in range(B)]
+    keys = ("total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg", "count_reg", "lambda_f_reg")
+    for i in range(B):
+        P, F, hist = res[i]
+        np.testing.assert_array_equal(P, solo[i][0], err_msg=f"fold {i}: batch != the mapping trained alone")
+        np.testing.assert_array_equal(F, solo[i][1], err_msg=f"fold {i}: filter")
+        for k in keys:
+            assert hist[k] == solo[i][2][k], (i, k)
+        kw, seed = fold(i)
+        M0, F0 = orc.reference_init_MF_constrained(C, V, seed)
+        o = orc.OracleMapperConstrained(kw["S"], kw["G"], kw["d"], M0=M0, F0=F0, target_count=tc, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(epochs, 0.1)
+        for k in keys:
+            ref = np.array([float(x) for x in ho[k]], dtype=np.float64)
+            err = np.abs(np.array([float(x) for x in hist[k]]) - ref).max()
+            assert err <= tol_loss * max(1.0, np.abs(ref).max()), (i, k, err)
+        assert np.abs(P - Po).max() <= tol_P and np.abs(F - Fo).max() <= tol_P, i
+    assert len({m._engine.logits()[3] for m in mappers}) == 1
+
+
+def test_batched_constrained_folds_emulated(sim):
+    check_batched_constrained("cpu", "fp32", C=14, K=9, V=70, B=3, epochs=5, tol_loss=1e-5, tol_P=2e-5)
+
+
 def test_batched_folds_emulated(sim):
     check_batched("cpu", "fp32", C=14, K=9, V=70, B=3, epochs=5, lam=dict(lambda_d=1, lambda_g1=1, lambda_g2=0.5), tol_loss=1e-5, tol_P=2e-5)
     check_batched("cpu", "bf16x3", C=10, K=6, V=40, B=2, epochs=3, lam=dict(lambda_d=1, lambda_g1=1, lambda_r=1e-3, lambda_l2=1e-5),

@@ -352,6 +352,16 @@ def test_batched_mappings(precision):
                       tol_loss=tol["loss"], tol_P=tol["P"])
 
 
+def test_batched_constrained_mappings():
+    """tg_batch of MapperConstrained handles on the GPU (cross_val with mode='constrained', utils.py:576-600): 6 folds in one launch
+    per kernel incl. the filter's Adam step and the re-folding of the new filters, bit-identical to the folds trained alone and
+    against the fp64 oracle; and a shape on the 256-wide tiles."""
+    from tests.test_batched import check_batched_constrained
+    tol = pc.TOL["bf16x3"]
+    check_batched_constrained(DEV, "bf16x3", C=40, K=50, V=1300, B=6, epochs=8, tol_loss=tol["loss"], tol_P=tol["P"])
+    check_batched_constrained(DEV, "bf16x3", C=4200, K=30, V=900, B=2, epochs=3, tol_loss=tol["loss"], tol_P=tol["P"])
+
+
 @pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "bf16x3"), (4, "bf16x3")])
 def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
     """The multi-GPU driver (tangram_amd.sharded; the C library issues kernels + three exchanges per step) with `world` shards of one problem as
