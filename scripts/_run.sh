@@ -1,3 +1,4 @@
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; rm -rf gpurun_out/*; export PYTHONUNBUFFERED=1
-bash scripts/gpu_ab.sh r03g_w4 "bf16x3" 3 "" keep
-python scripts/with_lib.py build/ab_w4.so -m pytest 2>/dev/null | tail -1
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; rm -rf gpurun_out/*
+bash scripts/gpu_final.sh final keep
+bash scripts/gpu_pmc.sh pmc_final bf16x3 traffic keep 2>&1 | tail -3
+bash scripts/gpu_pmc.sh pmc_final_bf16 bf16 traffic keep 2>&1 | tail -3
