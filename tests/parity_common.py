@@ -17,6 +17,11 @@ TOL = {
 }
 
 
+# The 500-epoch cases of the reference's own test grid are ill-conditioned: the reference's fp32 run drifts from its fp64 run (flat
+# valley).  Beyond the well-conditioned prefix an implementation is held to this multiple of that drift, term by term.
+OWN_SPREAD = 3.0
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
@@ -73,21 +78,23 @@ def check_against_golden(res, precision, full_length):
         assert well >= min(n, 50), f"{k}: fixture ill-conditioned from epoch {well}"
         err = float(np.abs(got[:well] - ref[:well]).max())
         assert err <= tol["loss"] * scale, f"{k}: max per-epoch |delta| {err:.3e} > {tol['loss'] * scale:.1e}"
-        if well < n and k == "total_loss":
+        if well < n:
+            # ... and over the WHOLE run EVERY term stays within OWN_SPREAD x the reference's own fp32-vs-fp64 drift on the case
+            # (measured: 1.0 - 2.2 x; round 2 held only total_loss, to 5 x)
             spread = float(np.abs(z["f32_hist_" + k][:n] - ref).max())
-            bound = max(tol["loss"] * scale, 5.0 * spread * (tol["loss"] / 1e-5))
+            bound = max(tol["loss"] * scale, OWN_SPREAD * spread * (tol["loss"] / 1e-5))
             err = float(np.abs(got - ref).max())
-            assert err <= bound, f"{k} (full run): max per-epoch |delta| {err:.3e} > {bound:.1e}"
+            assert err <= bound, f"{k} (full run): max per-epoch |delta| {err:.3e} > {bound:.1e} (the reference's own fp32 drift: {spread:.1e})"
     if full_length:
         dP = float(np.abs(res["P"] - z["f64_P"]).max())
         boundP = tol["P"]
         if res["mode"] == "grid":       # end point of an ill-conditioned 500-epoch run: relative to the reference's own fp32 spread
-            boundP = max(tol["P"], 5.0 * float(np.abs(z["f32_P"] - z["f64_P"]).max()) * (tol["P"] / 2e-4))
+            boundP = max(tol["P"], OWN_SPREAD * float(np.abs(z["f32_P"] - z["f64_P"]).max()) * (tol["P"] / 2e-4))
         assert dP <= boundP, f"max|dP| {dP:.3e} > {boundP:.1e}"
         rel = float(np.linalg.norm(res["Ghat"] - z["f64_Ghat"]) / np.linalg.norm(z["f64_Ghat"]))
         bound_g = tol["ghat"]
         if res["mode"] == "grid":
-            bound_g = max(bound_g, 5.0 * float(np.linalg.norm(z["f32_Ghat"] - z["f64_Ghat"]) / np.linalg.norm(z["f64_Ghat"])) * (tol["ghat"] / 1e-4))
+            bound_g = max(bound_g, OWN_SPREAD * float(np.linalg.norm(z["f32_Ghat"] - z["f64_Ghat"]) / np.linalg.norm(z["f64_Ghat"])) * (tol["ghat"] / 1e-4))
         assert rel <= bound_g, f"relFro(P^T S) {rel:.3e} > {bound_g:.1e}"
         if res["F"] is not None:
             dF = float(np.abs(res["F"] - z["f64_F_out"]).max())

@@ -47,6 +47,38 @@ def test_argument_errors_are_reported_not_aborted():
     assert sizes.m_pitch == 64 and sizes.state_bytes > 0 and sizes.workspace_bytes > 0
 
 
+def test_configuration_errors_of_round_three_fields():
+    """bwd_tile and the shard geometry of runs with spatial terms are validated on the host (tg_query_sizes, no GPU involved)."""
+    from tangram_amd import _build, _capi
+    lib = _capi._declare(ctypes.CDLL(_build.build()))
+    sizes = _capi.TgSizes()
+
+    def cfg(**kw):
+        c = _capi.TgConfig()
+        c.abi_version = _capi.TG_ABI_VERSION
+        c.n_cells, c.n_genes, c.n_spots, c.lambda_g1 = 5000, 40, 1000, 1.0
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    assert lib.tg_query_sizes(ctypes.byref(cfg()), ctypes.byref(sizes)) == 0
+    assert lib.tg_query_sizes(ctypes.byref(cfg(bwd_tile=64)), ctypes.byref(sizes)) == -1 and b"bwd_tile" in lib.tg_last_error()
+    for t in (128, 256):
+        assert lib.tg_query_sizes(ctypes.byref(cfg(bwd_tile=t)), ctypes.byref(sizes)) == 0
+    # spatial terms on a spot shard: blocks of ceil(V_total / ranks) spots, the offset names the block
+    sp = dict(lambda_neighborhood_g1=0.5, nnz_w=7000, n_spots_total=1000, n_ranks=3)      # blocks of 334, 334, 332
+    assert lib.tg_query_sizes(ctypes.byref(cfg(n_spots=334, spot_offset=334, **sp)), ctypes.byref(sizes)) == 0
+    assert lib.tg_query_sizes(ctypes.byref(cfg(n_spots=332, spot_offset=668, **sp)), ctypes.byref(sizes)) == 0
+    full = sizes.workspace_bytes
+    assert lib.tg_query_sizes(ctypes.byref(cfg(n_spots=333, spot_offset=333, **sp)), ctypes.byref(sizes)) == -1      # balanced partition: refused
+    assert b"ceil" in lib.tg_last_error()
+    assert lib.tg_query_sizes(ctypes.byref(cfg(n_spots=334, spot_offset=334, lambda_neighborhood_g1=0.5, nnz_w=7000, n_spots_total=1000)),
+                              ctypes.byref(sizes)) == -1                                                           # n_ranks missing
+    # the gathered matrices are part of the workspace: a shard with spatial terms needs more than the same shard without
+    assert lib.tg_query_sizes(ctypes.byref(cfg(n_spots=334, n_spots_total=1000, n_ranks=3)), ctypes.byref(sizes)) == 0
+    assert sizes.workspace_bytes < full
+
+
 def test_product_path_has_no_cpu_fallback():
     import numpy as np
     from tangram_amd import _capi
