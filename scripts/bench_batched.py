@@ -16,27 +16,40 @@ from tangram_amd.synthetic import make_workload  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", default="2,4,8,16", help="batch sizes of the stepping-rate part")
+    ap.add_argument("--epochs", type=int, default=1000)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the train_many part (e.g. under rocprofv3)")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-fold stepping rate (a profile of one batch size only)")
+    ap.add_argument("--constrained", action="store_true", help="MapperConstrained folds instead of Mapper")
+    opt = ap.parse_args()
     dev = "cuda:0"
-    C, K, V, N, EPOCHS = 18, 250, 9852, 16, 1000
+    C, K, V, N, EPOCHS = 18, 250, 9852, 16, opt.epochs
     w = make_workload(C, K + N, V, dev, seed=1)
     S_all, G_all, d = w["S"].cpu().numpy(), w["G"].cpu().numpy(), w["d"].cpu().numpy()
     ds = np.full(C, 1.0 / C, np.float32)
 
     def builder(i):          # leave-one-gene-out fold i (cross_val, utils.py:576-600)
         keep = [g for g in range(K + N) if g != i][:K]
+        if opt.constrained:
+            return lambda: mo.MapperConstrained(S=S_all[:, keep], G=G_all[:, keep], d=d, lambda_d=1, lambda_count=1, lambda_f_reg=1, target_count=C // 2,
+                                                device=dev, random_state=i + 1)
         return lambda: mo.Mapper(S=S_all[:, keep], G=G_all[:, keep], d=d, d_source=ds, lambda_d=1, device=dev, random_state=i + 1)     # (0 would mean "unseeded", like the reference)
 
     out = {"epochs": EPOCHS, "shape": [C, K, V]}
     # --- pure stepping rate: one fold alone, then B folds per launch
-    m1 = builder(0)()
-    m1._engine.step(100, 0.1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m1._engine.step(EPOCHS, 0.1)
-    torch.cuda.synchronize()
-    t1 = (time.perf_counter() - t0) / EPOCHS
-    out["one_fold_us_per_iter"] = 1e6 * t1
-    for B in (2, 4, 8, 16):
+    t1 = float("nan")
+    if not opt.no_single:
+        m1 = builder(0)()
+        m1._engine.step(100, 0.1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m1._engine.step(EPOCHS, 0.1)
+        torch.cuda.synchronize()
+        t1 = (time.perf_counter() - t0) / EPOCHS
+        out["one_fold_us_per_iter"] = 1e6 * t1
+    for B in [int(x) for x in opt.batches.split(",") if x]:
         ms = [builder(i)() for i in range(B)]
         batch = MapperBatch(ms)
         batch.step(100, 0.1)
@@ -49,6 +62,9 @@ def main():
         batch.close()
         for m in ms:
             m.release()
+    if opt.no_e2e:
+        print(json.dumps(out))
+        return
     # --- end to end through train_many (construction, training, result copies), 16 folds
     builders = [builder(i) for i in range(N)]
     torch.cuda.synchronize()

@@ -125,6 +125,8 @@ struct TgLayout {
     // spots (only the last one shorter), so that the gathered blocks ARE the global matrix.  Vsr = rows allocated (>= Vs).
     int Vs, Vsr, Vmaxl, sp_shard, nrb_s;
     size_t o_GhatFull, o_Gfull;
+    int smallc;                                       // C <= 32 (clusters mode): the iteration runs on tg_sc_forward / tg_sc_backward
+    size_t o_Ssmall, o_Stsmall;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
     int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
@@ -264,6 +266,14 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     L->o_X = take((size_t)L->C * L->Vp * 4);
     L->o_gfrac = take((size_t)L->Kp * 4);
     L->o_rowent = take((size_t)L->Cp * 4);
+    // small-C path (tg_kernels.h): single GPU, rows within the one-kernel update, no spatial terms (their extra gradient rides dGhat)
+    L->smallc = (L->C <= TG_SC_MAXC && !spatial && !L->sp_shard && cfg->n_ranks == 0 && L->Vtot == L->V && L->bands == 1 &&
+                 L->V <= TG_ROWPASS_MAX_V && cfg->tile_size == 0) ? 1 : 0;
+    if (L->smallc) {
+        const size_t cm = (size_t)tg_sc_cm(L->C);
+        L->o_Ssmall = take(cm * L->Kp * 4);                            // Sa
+        L->o_Stsmall = take((size_t)16 * ((cm + 15) / 16) * L->Kp * 4);    // Sx
+    }
     if (L->sp_shard) {
         L->o_GhatFull = take((size_t)L->Vsr * L->Kp * 4);
         L->o_Gfull = take((size_t)L->Vsr * L->Kp * 4);
@@ -378,6 +388,20 @@ static int tg_lds_attr() {
     return TG_OK;
 }
 
+// small-C path: one switch over the compile-time cluster bound (C rounded up to a multiple of 4) and the per-spot-sums flag
+#define TG_SC_DISPATCH(C, VOX, STMT)                                                                               \
+    do {                                                                                                           \
+        switch (tg_sc_cm(C)) {                                                                                     \
+        case 4: if (VOX) { STMT(4, true); } else { STMT(4, false); } break;                                        \
+        case 8: if (VOX) { STMT(8, true); } else { STMT(8, false); } break;                                        \
+        case 12: if (VOX) { STMT(12, true); } else { STMT(12, false); } break;                                     \
+        case 16: if (VOX) { STMT(16, true); } else { STMT(16, false); } break;                                     \
+        case 20: if (VOX) { STMT(20, true); } else { STMT(20, false); } break;                                     \
+        case 24: if (VOX) { STMT(24, true); } else { STMT(24, false); } break;                                     \
+        case 28: if (VOX) { STMT(28, true); } else { STMT(28, false); } break;                                     \
+        default: if (VOX) { STMT(32, true); } else { STMT(32, false); } break;                                     \
+        }                                                                                                          \
+    } while (0)
 // ---- set-up ------------------------------------------------------------------------------------
 template <class PR>
 static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
@@ -392,6 +416,12 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     TG_LAUNCH((tg_prep_sk<PR>), (n1 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH_CK();
+    if (L.smallc) {
+        const int cm = tg_sc_cm(L.C);
+        TG_LAUNCH(tg_prep_ssmall, (16 * ((cm + 15) / 16) * L.Kp + 255) / 256, 1, 256, 0, m->stream, in->S_dev, (long long)L.K, a.aug, L.C, cm, L.K, L.Kp, m->fp(L.o_Ssmall),
+                  m->fp(L.o_Stsmall));
+        TG_LAUNCH_CK();
+    }
     if (L.T == 256) { const int rc = tg_lds_attr<PR, TgGeoSmall>(); if (rc != TG_OK) return rc; }     // (the backward GEMM may run on 128^2 tiles)
     return L.T == 256 ? tg_lds_attr<PR, TgGeoLarge>() : tg_lds_attr<PR, TgGeoSmall>();
 }
@@ -942,7 +972,7 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     const bool whole = c1 < 0;
     if (whole) { stream = m->stream; c0 = 0; c1 = L.C; }
     TgUpdateArgs u = tg_update_args(m, lr, finalize, c0, c1);
-    const bool x16 = (m->cfg.precision == TG_PREC_BF16);     // PrecBF16::X16
+    const bool x16 = (m->cfg.precision == TG_PREC_BF16) && !L.smallc;     // PrecBF16::X16 (the small-C kernels store X in fp32)
     u.fin_on = 0;
     int extra_wg = 0;
     if (m->fin_pending && whole) { u.fin = m->fin_args; u.fin_on = 1; extra_wg = 1; m->fin_pending = false; }
@@ -963,9 +993,64 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
     return TG_OK;
 }
 
+// ---- small-C path (clusters mode) ---------------------------------------------------------------------------------
+static TgSmallArgs tg_small_args(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    TgFinalizeArgs f;
+    TgEmitArgs e;
+    tg_loss_args(m, hist_row, f, e);
+    f.nky = (L.Kp + TG_SC_KC - 1) / TG_SC_KC;     // tg_sc_forward: one block of per-spot statistics per gene chunk
+    TgSmallArgs a;
+    a.M = (const float*)(m->st + L.s_M); a.rmax = m->fp(L.o_rshift); a.rmul = m->fp(L.o_rmul);
+    a.Sa = m->fp(L.o_Ssmall); a.Sx = m->fp(L.o_Stsmall); a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
+    a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat); a.X = m->fp(L.o_X);
+    a.C = L.C; a.CM = tg_sc_cm(L.C); a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = (m->cfg.lambda_g2 != 0.f);
+    a.fin = f;
+    return a;
+}
+static int tg_small_nblk(const TgLayout& L) { return (L.V + TG_SC_SB - 1) / TG_SC_SB; }        // blocks of 64 spots = rows of genepart
+
+// forward + statistics, backward of one iteration on the small-C kernels; the history scalars are left to the extra workgroup of the
+// update kernel like on the GEMM path (fin_pending)
+static int tg_launch_small(tg_mapper* m, float* hist_row) {
+    const TgLayout& L = m->L;
+    const TgSmallArgs a = tg_small_args(m, hist_row);
+    const int nblk = tg_small_nblk(L), nch = (L.Kp + TG_SC_KC - 1) / TG_SC_KC;
+#define TG_SC_FWD(CM, VX) TG_LAUNCH((tg_sc_forward<CM, VX>), nblk, nch, TG_SC_KC, tg_sc_lds_fwd(), m->stream, a)
+    TG_SC_DISPATCH(L.C, a.want_vox, TG_SC_FWD);
+#undef TG_SC_FWD
+    tg_prof_mark(m, "tg_sc_forward");
+    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nblk, L.Kp,
+              m->fp(L.o_genestat));
+    tg_prof_mark(m, "tg_gene_reduce");
+    m->fin_args = a.fin; m->fin_pending = true;
+#define TG_SC_BWD(CM, VX) TG_LAUNCH((tg_sc_backward<CM>), nblk, 1, TG_SC_KC, tg_sc_lds_bwd(), m->stream, a)
+    TG_SC_DISPATCH(L.C, false, TG_SC_BWD);
+#undef TG_SC_BWD
+    tg_prof_mark(m, "tg_sc_backward");
+    return TG_OK;
+}
+
 template <class PR>
 static int tg_one_step(tg_mapper* m, float lr, float* hist_row) {
     int rc;
+    if (m->L.smallc) {
+        const bool constrained = (m->cfg.mode == TG_MODE_CONSTRAINED);
+        if ((rc = tg_launch_small(m, hist_row))) return rc;
+        if (tg_launch_failed()) return tg_launch_status();
+        if ((rc = tg_launch_update(m, lr, !constrained, nullptr, 0, -1, true))) return rc;
+        if (m->L.full) {
+            tg_launch_hist_regs(m, m->stream, hist_row);
+            tg_prof_mark(m, "tg_hist_regs");
+        }
+        if (constrained) {
+            if ((rc = tg_launch_filter(m, true, lr, hist_row))) return rc;
+            if ((rc = tg_merge(m, m->fp(m->L.o_rowpair), 1, true, false))) return rc;
+        }
+        m->step += 1;
+        TG_LAUNCH_CK();
+        return TG_OK;
+    }
     if ((rc = tg_launch_forward<PR>(m))) return rc;
     if ((rc = tg_launch_ghat_stats(m))) return rc;
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;
@@ -1042,7 +1127,7 @@ static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool f
 struct tg_batch {
     std::vector<tg_mapper*> h;
     unsigned char* dev;                              // caller-provided scratch: the argument arrays
-    size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, o_filt, o_merge, o_scr, total;
+    size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, o_filt, o_merge, o_scr, o_small, total;
     std::vector<float*> hist;                        // history base pointers the argument arrays currently hold
     bool args_valid;
 };
@@ -1052,8 +1137,8 @@ static size_t tg_batch_layout(int n, tg_batch* b) {
     const size_t o_fwd = take(n * sizeof(TgFwdArgs)), o_ghat = take(n * sizeof(TgGhatReduceArgs)), o_gene = take(n * sizeof(TgGeneReduceArgs)),
                  o_emit = take(n * sizeof(TgEmitArgs)), o_bwd = take(n * sizeof(TgBwdArgs)), o_upd = take(n * sizeof(TgUpdateArgs)),
                  o_hreg = take(n * sizeof(TgHistRegArgs)), o_filt = take(n * sizeof(TgFilterArgs)), o_merge = take(n * sizeof(TgMergeArgs)),
-                 o_scr = take(n * sizeof(float*));
-    if (b) { b->o_fwd = o_fwd; b->o_ghat = o_ghat; b->o_gene = o_gene; b->o_emit = o_emit; b->o_bwd = o_bwd; b->o_upd = o_upd; b->o_hreg = o_hreg;
+                 o_scr = take(n * sizeof(float*)), o_small = take(n * sizeof(TgSmallArgs));
+    if (b) { b->o_small = o_small; b->o_fwd = o_fwd; b->o_ghat = o_ghat; b->o_gene = o_gene; b->o_emit = o_emit; b->o_bwd = o_bwd; b->o_upd = o_upd; b->o_hreg = o_hreg;
              b->o_filt = o_filt; b->o_merge = o_merge; b->o_scr = o_scr; b->total = off; }
     return off;
 }
@@ -1092,7 +1177,7 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
     const int n = (int)b->h.size();
     std::vector<TgFwdArgs> fw(n); std::vector<TgGhatReduceArgs> gh(n); std::vector<TgGeneReduceArgs> gr(n);
     std::vector<TgEmitArgs> em(n); std::vector<TgBwdArgs> bw(n); std::vector<TgUpdateArgs> up(n); std::vector<TgHistRegArgs> hr(n);
-    std::vector<TgFilterArgs> fl(n); std::vector<TgMergeArgs> mg(n); std::vector<float*> scr(n);
+    std::vector<TgFilterArgs> fl(n); std::vector<TgMergeArgs> mg(n); std::vector<float*> scr(n); std::vector<TgSmallArgs> sm(n);
     const bool constrained = (b->h[0]->cfg.mode == TG_MODE_CONSTRAINED);
     for (int i = 0; i < n; ++i) {
         tg_mapper* m = b->h[i];
@@ -1106,6 +1191,12 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
         f.hist = hist ? hist[i] : nullptr;                      // BASE of the mapping's history (row offset: TgStepVar)
         em[i].fin = f;
         bw[i] = tg_bwd_args<PR>(m, 0, L.nct, &grid);
+        if (L.smallc) {                                             // clusters mode: tg_sc_forward / tg_sc_backward take the place of the GEMMs
+            sm[i] = tg_small_args(m, nullptr);
+            sm[i].fin.hist = f.hist;
+            f = sm[i].fin;                                          // (one block of per-spot statistics: nky = 1)
+            gr[i].nrb = tg_small_nblk(L);
+        }
         up[i] = tg_update_args(m, 0.f, !constrained, 0, L.C);       // (MapperConstrained: tg_merge_stats folds the NEW filter in afterwards)
         up[i].fin = f; up[i].fin_on = 1;
         hr[i] = TgHistRegArgs{m->fp(L.o_rowq), L.C, hist ? hist[i] : nullptr, m->cfg.lambda_r, m->cfg.lambda_l1, m->cfg.lambda_l2, constrained ? 1 : 0};
@@ -1127,6 +1218,7 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
     TG_CK(tg_memcpy_h2d(b->dev + b->o_filt, fl.data(), n * sizeof(TgFilterArgs), s));
     TG_CK(tg_memcpy_h2d(b->dev + b->o_merge, mg.data(), n * sizeof(TgMergeArgs), s));
     TG_CK(tg_memcpy_h2d(b->dev + b->o_scr, scr.data(), n * sizeof(float*), s));
+    TG_CK(tg_memcpy_h2d(b->dev + b->o_small, sm.data(), n * sizeof(TgSmallArgs), s));
 #ifndef TG_SIM
     TG_CK(hipStreamSynchronize(s));        // (the host vectors go out of scope; once per tg_batch_step call, not per iteration)
 #endif
@@ -1160,7 +1252,7 @@ static int tg_batch_step_impl(tg_batch* b, int n_steps, float lr, float* const* 
     const TgLayout& L = m0->L;
     tg_stream_t s = m0->stream;
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
-    const bool x16 = (m0->cfg.precision == TG_PREC_BF16);
+    const bool x16 = (m0->cfg.precision == TG_PREC_BF16) && !L.smallc;
     int gf, gb;
     (void)tg_fwd_args<PR>(m0, -1, nullptr, false, &gf);
     (void)tg_bwd_args<PR>(m0, 0, L.nct, &gb);
@@ -1171,7 +1263,19 @@ static int tg_batch_step_impl(tg_batch* b, int n_steps, float lr, float* const* 
     const TgBwdArgs* a_bw = (const TgBwdArgs*)(b->dev + b->o_bwd);
     const TgUpdateArgs* a_up = (const TgUpdateArgs*)(b->dev + b->o_upd);
     const TgHistRegArgs* a_hr = (const TgHistRegArgs*)(b->dev + b->o_hreg);
+    const TgSmallArgs* a_sm = (const TgSmallArgs*)(b->dev + b->o_small);
+    const int nblk = tg_small_nblk(L), sc_nch = (L.Kp + TG_SC_KC - 1) / TG_SC_KC;
+    const bool want_vox = (m0->cfg.lambda_g2 != 0.f);
     for (int it = 0; it < n_steps; ++it) {
+        if (L.smallc) {
+#define TG_SC_FWD_B(CM, VX) TG_LAUNCH3((tg_sc_forward_b<CM, VX>), nblk, sc_nch, n, TG_SC_KC, tg_sc_lds_fwd(), s, a_sm)
+            TG_SC_DISPATCH(L.C, want_vox, TG_SC_FWD_B);
+#undef TG_SC_FWD_B
+            TG_LAUNCH3(tg_gene_reduce_b, (L.Kp + 63) / 64, 1, n, 1024, TG_GR_GROUPS * 64 * 2 * 4, s, a_gr);
+#define TG_SC_BWD_B(CM, VX) TG_LAUNCH3((tg_sc_backward_b<CM>), nblk, 1, n, TG_SC_KC, tg_sc_lds_bwd(), s, a_sm)
+            TG_SC_DISPATCH(L.C, false, TG_SC_BWD_B);
+#undef TG_SC_BWD_B
+        } else {
         if (L.fwd_wide) {
             if constexpr (PR::NP == 2) TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoWide>), gf, 1, n, TgGeoWide::NT, TgGeoWide::LDS_BYTES, s, a_fwd);
         } else if (L.T == 256) TG_LAUNCH3((tg_fwd_kernel_b<PR, TgGeoLarge>), gf, 1, n, TgGeoLarge::NT, TgGeoLarge::LDS_BYTES, s, a_fwd);
@@ -1181,6 +1285,7 @@ static int tg_batch_step_impl(tg_batch* b, int n_steps, float lr, float* const* 
         TG_LAUNCH3((tg_dghat_emit_b<PR>), nrb, 1, n, 256, (2 * L.Kp + 2 * TG_RB) * 4, s, a_em);
         if (L.T == 256) TG_LAUNCH3((tg_bwd_kernel_b<PR, TgGeoLarge>), gb, 1, n, TgGeoLarge::NT, TgGeoLarge::BWD_LDS_BYTES, s, a_bw);
         else TG_LAUNCH3((tg_bwd_kernel_b<PR, TgGeoSmall>), gb, 1, n, TgGeoSmall::NT, TgGeoSmall::BWD_LDS_BYTES, s, a_bw);
+        }
         const double t = (double)(m0->step + 1);
         TgStepVar var;
         var.step_size = (float)((double)lr / (1.0 - pow((double)m0->cfg.beta1, t)));
@@ -1659,6 +1764,6 @@ extern "C" int tg_debug_layout(const tg_config* cfg, int* out) {
     TgLayout L;
     const int rc = tg_make_layout(cfg, &L);
     if (rc != TG_OK) return rc;
-    out[0] = L.T; out[1] = L.nct; out[2] = L.nvt; out[3] = L.nkt; out[4] = L.nsplit; out[5] = L.fwd_wide; out[6] = L.bands; out[7] = 0;
+    out[0] = L.T; out[1] = L.nct; out[2] = L.nvt; out[3] = L.nkt; out[4] = L.nsplit; out[5] = L.fwd_wide; out[6] = L.bands; out[7] = L.smallc;
     return TG_OK;
 }

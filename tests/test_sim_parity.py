@@ -297,6 +297,25 @@ def test_emulated_random_configurations(sim, case):
     assert np.abs(P.numpy() - Po).max() <= tol["P"], (case, C, K, V, precision)
 
 
+# (C, K, V, constrained, lambda_g2): cluster counts around the compile-time bounds (multiples of 4, max 32), gene counts of one chunk,
+# a partial second chunk (K = 300 pads to 384) and three chunks, spot counts around the 64-spot block
+SMALL_C_CASES = [
+    (5, 40, 70, False, 0.0), (18, 250, 330, False, 0.0), (18, 250, 130, True, 0.5), (32, 300, 129, False, 0.7),
+    (20, 600, 64, False, 0.0), (3, 1, 1, False, 0.5), (12, 127, 200, True, 0.0), (29, 20, 63, False, 1.0),
+]
+
+
+@pytest.mark.parametrize("i", range(len(SMALL_C_CASES)))
+def test_emulated_small_cluster_path(sim, i):
+    """The clusters-mode kernels (tg_sc_softmax / tg_sc_forward / tg_sc_backward) against the fp64 oracle."""
+    C, K, V, constrained, g2 = SMALL_C_CASES[i]
+    pc.small_cluster_case("cpu", C, K, V, constrained, g2, seed=300 + i)
+
+
+def test_emulated_tile_size_pins_the_gemm_path(sim):
+    pc.small_cluster_case("cpu", 18, 250, 130, False, 0.5, seed=311, precision="fp32", tile_size=128)
+
+
 @pytest.mark.parametrize("precision,rtol", [("fp32", 2e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)])
 def test_emulated_project_genes_all_genes(sim, precision, rtol):
     """tg_mapper_project_genes: softmax(M)^T S_all over a gene set wider than the training genes (several blocks of
