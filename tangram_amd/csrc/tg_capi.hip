@@ -126,7 +126,7 @@ struct TgLayout {
     int Vs, Vsr, Vmaxl, sp_shard, nrb_s;
     size_t o_GhatFull, o_Gfull;
     int smallc;                                       // C <= 32 (clusters mode): the iteration runs on tg_sc_forward / tg_sc_backward
-    size_t o_Ssmall, o_Stsmall;
+    size_t o_Ssmall, o_Stsmall, o_spotpart;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
     int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
@@ -271,6 +271,7 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
                  L->V <= TG_ROWPASS_MAX_V && cfg->tile_size == 0) ? 1 : 0;
     if (L->smallc) {
         const size_t cm = (size_t)tg_sc_cm(L->C);
+        L->o_spotpart = take((size_t)((L->V + TG_SC_SB - 1) / TG_SC_SB) * 2 * 4);
         L->o_Ssmall = take(cm * L->Kp * 4);                            // Sa
         L->o_Stsmall = take((size_t)16 * ((cm + 15) / 16) * L->Kp * 4);    // Sx
     }
@@ -806,6 +807,7 @@ static void tg_loss_args(tg_mapper* m, float* hist_row, TgFinalizeArgs& f, TgEmi
     f.ctpart = L.has_ct ? m->fp(L.o_ctpart) : nullptr; f.n_ctpart = L.Vs; f.V_sp = L.Vs;
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
     f.part_out = m->comm ? m->fp(L.o_rowpair) + 2 * (size_t)L.C : nullptr;       // spot shard: this rank's parts of the spot sums
+    f.spotpart = nullptr; f.n_spotpart = 0;
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
     // (spot shard: the extra gradient is evaluated for ALL spots; this handle's rows start at its spot offset)
@@ -1000,6 +1002,7 @@ static TgSmallArgs tg_small_args(tg_mapper* m, float* hist_row) {
     TgEmitArgs e;
     tg_loss_args(m, hist_row, f, e);
     f.nky = (L.Kp + TG_SC_KC - 1) / TG_SC_KC;     // tg_sc_forward: one block of per-spot statistics per gene chunk
+    f.spotpart = m->fp(L.o_spotpart); f.n_spotpart = (L.V + TG_SC_SB - 1) / TG_SC_SB;
     TgSmallArgs a;
     a.M = (const float*)(m->st + L.s_M); a.rmax = m->fp(L.o_rshift); a.rmul = m->fp(L.o_rmul);
     a.Sa = m->fp(L.o_Ssmall); a.Sx = m->fp(L.o_Stsmall); a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);

@@ -549,6 +549,8 @@ struct TgFinalizeArgs {
     int V_sp;                  // spots the spatial sums (ct islands) run over: V, or ALL spots on a spot shard (the spatial terms are
                                // evaluated on the gathered Ghat there, identically on every rank)
     float* part_out;           // spot shards: [0] = this rank's part of the voxel score (sum_v cos / V_total), [1] = of the KL sum; or null
+    float* spotpart; int n_spotpart;     // clusters-mode kernels: [blocks of 64 spots][2] sums of the per-spot (cosine, KL) terms, left by
+                                         // tg_sc_backward (which evaluates tg_spot_coef anyway); null: tg_loss_scalars walks the spots itself
 };
 
 TG_DEV float tg_block_sum_1024(float x, float* red) {
@@ -647,8 +649,10 @@ TG_DEV void tg_loss_scalars(const TgFinalizeArgs& a, float* red) {
 
     float vs = 0.f, kl = 0.f;
     const float rho_scale = a.fsum_dev ? 1.f / a.fsum_dev[0] : a.rho_scale;
+    if (!WRITE && a.spotpart)
+        for (int i = t; i < a.n_spotpart; i += nt) { vs += a.spotpart[2 * i]; kl += a.spotpart[2 * i + 1]; }
     // (4 spots per trip with all their loads issued first: this single-workgroup loop is pure memory latency)
-    for (int vb0 = t; vb0 < a.Vr; vb0 += 4 * nt) {
+    else for (int vb0 = t; vb0 < a.Vr; vb0 += 4 * nt) {
         float dot[4], n2a[4], n2b[4], colsum[4], dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) tg_spot_stats_load(a, vb0 + u * nt, dot[u], n2a[u], n2b[u], colsum[u], dv[u]);
@@ -1473,13 +1477,18 @@ TG_DEV void tg_sc_backward_body(const TgSmallArgs& a) {
     float va_t = 0.f, vb_t = 0.f, av_t = 0.f;
     if (t < TG_SC_SB) {                                          // per-spot coefficients, like tg_dghat_emit<SELF>
         const int v = v0 + t;
+        float c = 0.f, kl = 0.f;
         if (v < a.V) {
-            float dot, n2a, n2b, colsum, dv, c = 0.f, kl = 0.f;
+            float dot, n2a, n2b, colsum, dv;
             tg_spot_stats_load(a.fin, v, dot, n2a, n2b, colsum, dv);
             const float rho_scale = a.fin.fsum_dev ? 1.f / a.fin.fsum_dev[0] : a.fin.rho_scale;
             tg_spot_coef(a.fin, dot, n2a, n2b, colsum, dv, rho_scale, va_t, vb_t, av_t, c, kl);
         }
         cs[t] = va_t; cs[TG_SC_SB + t] = vb_t;
+        // the spots' terms of the loss (voxel cosine, KL) summed over the block: the history workgroup adds the blocks up
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { c += tg_shfl_xor(c, m); kl += tg_shfl_xor(kl, m); }
+        if (t == 0) { a.fin.spotpart[2 * blockIdx.x] = c; a.fin.spotpart[2 * blockIdx.x + 1] = kl; }
     }
     tg_sc_p_tile<CM>(a, v0, wave, lane, Pt);
     *(f32x4*)(coef + lane * 4) = cval;
