@@ -54,7 +54,9 @@ typedef enum tg_precision {
 typedef struct tg_config {
     int32_t abi_version;     /* TG_ABI_VERSION */
     int32_t mode;            /* tg_mode */
-    int32_t precision;       /* tg_precision of the two GEMMs */
+    int32_t precision;       /* tg_precision of the two GEMMs (problems with n_cells <= 32 on one GPU without spatial terms run on
+                                exact-fp32 matrix-core kernels that recompute P^T S instead of storing it, whatever this says;
+                                tile_size != 0 pins the GEMM kernels there too) */
     int32_t n_cells;         /* C: rows of S and M */
     int32_t n_genes;         /* K: training genes */
     int32_t n_spots;         /* V: spots held by THIS handle (a shard when spots are partitioned) */
