@@ -6,5 +6,6 @@ from .mapping_utils import map_cells_to_space, adata_to_cluster_expression, dens
 from . import preprocess                                          # noqa: F401
 from .utils import project_genes                                  # noqa: F401
 from .batched import train_many, MapperBatch                                   # noqa: F401
+from .cross_validation import cross_val, cv_data_gen                        # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,190 @@
+"""
+`cross_val` / `cv_data_gen` with the reference's signatures (tangram/utils.py:462-668), built on the batched mappings of
+SURVEY section 8, f-3.
+
+The reference trains one mapping per held-out gene (or per tenth of the genes) strictly one after the other, each through
+`map_cells_to_space(cv_train_genes=...)`, then projects the fold's genes on the host (`project_genes`) and scores them
+(`compare_spatial_geneexp`).  Here the training-gene matrices are uploaded ONCE, a fold is a column subset gathered on the device,
+`folds_per_launch` folds advance in one launch per kernel (`tangram_amd.batched.train_many` -> `tg_batch`), and a fold's held-out
+genes are projected by its mapper while the mapping is still resident in HBM.  Every fold's mapping is the bits of
+`map_cells_to_space(cv_train_genes=train_genes, ...)` on the same inputs; scores agree to fp32 rounding of the projection.
+
+Deviations a caller can see: no tqdm bar; the root / anndata loggers are not disabled; `np.float` (removed from NumPy) is `float`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import mapping_optimizer as mo
+from .anndata_lite import make_result_anndata
+from .batched import train_many
+from .mapping_utils import (_all_genes_expressed, _training_matrix, adata_to_cluster_expression, annotate_gene_sparsity)
+
+
+def cv_data_gen(adata_sc, adata_sp, cv_mode="loo"):
+    """Generates (train_genes, test_genes) pairs: leave-one-out or 10 contiguous folds of `uns['training_genes']`
+    (reference tangram/utils.py:462-500; sklearn's LeaveOneOut / unshuffled KFold(10))."""
+    if "training_genes" not in adata_sc.uns.keys():
+        raise ValueError("Missing tangram parameters. Run `pp_adatas()`.")
+    if "training_genes" not in adata_sp.uns.keys():
+        raise ValueError("Missing tangram parameters. Run `pp_adatas()`.")
+    if not list(adata_sp.uns["training_genes"]) == list(adata_sc.uns["training_genes"]):
+        raise ValueError("Unmatched training_genes field in two Anndatas. Run `pp_adatas()`.")
+    genes = np.array(adata_sp.uns["training_genes"])
+    n = len(genes)
+    if cv_mode == "loo":
+        bounds = [(i, i + 1) for i in range(n)]
+    elif cv_mode == "10fold":
+        if n < 10:                                              # (what sklearn's KFold raises)
+            raise ValueError("Cannot have number of splits n_splits=10 greater than the number of samples: n_samples={}.".format(n))
+        sizes = np.full(10, n // 10)
+        sizes[: n % 10] += 1
+        ends = np.cumsum(sizes)
+        bounds = list(zip(ends - sizes, ends))
+    else:
+        raise ValueError("cv_mode must be 'loo' or '10fold'")
+    for lo, hi in bounds:
+        yield list(genes[:lo]) + list(genes[hi:]), list(genes[lo:hi])
+
+
+def _to_device(x, device):
+    return (x if torch.is_tensor(x) else torch.as_tensor(np.ascontiguousarray(x))).to(device=device, dtype=torch.float32)
+
+
+def cross_val(
+    adata_sc,
+    adata_sp,
+    cluster_label=None,
+    mode="clusters",
+    scale=True,
+    lambda_d=0,
+    lambda_g1=1,
+    lambda_g2=0,
+    lambda_r=0,
+    lambda_count=1,
+    lambda_f_reg=1,
+    target_count=None,
+    num_epochs=1000,
+    device="cuda:0",
+    learning_rate=0.1,
+    cv_mode="loo",
+    return_gene_pred=False,
+    density_prior=None,
+    random_state=None,
+    verbose=False,
+    *,
+    gemm_precision="bf16x3",
+    folds_per_launch=16,
+):
+    """Executes cross validation; arguments and returns as the reference (tangram/utils.py:503-668):
+    `cv_dict` {'avg_test_score', 'avg_train_score'} and, with `return_gene_pred` in 'loo' mode, `adata_ge_cv` (the held-out
+    genes' predicted spatial expression, spots x genes, `var['test_score']`) and `test_gene_df` ('score', 'is_training',
+    'sparsity_sp', 'sparsity_sc', 'sparsity_diff').
+
+    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer), `folds_per_launch`: folds trained together (tg_batch)."""
+    # ---- the argument handling of map_cells_to_space (mapping_utils.py:205-229, :280-307), once for all folds
+    if lambda_g1 == 0:
+        raise ValueError("lambda_g1 cannot be 0.")
+    if (type(density_prior) is str) and (density_prior not in ["rna_count_based", "uniform", None]):
+        raise ValueError("Invalid input for density_prior.")
+    if density_prior is not None and (lambda_d == 0 or lambda_d is None):
+        lambda_d = 1
+    if lambda_d > 0 and density_prior is None:
+        raise ValueError("When lambda_d is set, please define the density_prior.")
+    if mode not in ["clusters", "cells", "constrained"]:
+        raise ValueError('Argument "mode" must be "cells", "clusters" or "constrained')
+    if mode == "clusters" and cluster_label is None:
+        raise ValueError("A cluster_label must be specified if mode is 'clusters'.")
+    if mode == "constrained" and not all([target_count, lambda_f_reg, lambda_count]):
+        raise ValueError("target_count, lambda_f_reg and lambda_count must be specified if mode is 'constrained'.")
+    folds = list(cv_data_gen(adata_sc, adata_sp, cv_mode))
+    if not set(["training_genes", "overlap_genes"]).issubset(set(adata_sc.uns.keys())) or \
+            not set(["training_genes", "overlap_genes"]).issubset(set(adata_sp.uns.keys())):
+        raise ValueError("Missing tangram parameters. Run `pp_adatas()`.")
+    device = torch.device(device)
+
+    # the single-cell side every fold trains on and is scored against (:557-558 and mapping_utils.py:231-234)
+    adata_src = adata_to_cluster_expression(adata_sc, cluster_label, scale, add_density=True, device=device) if mode == "clusters" else adata_sc
+    genes = list(adata_sc.uns["training_genes"])
+    pos = {g: i for i, g in enumerate(genes)}
+    S_all = _training_matrix(adata_src, adata_src[:, genes], genes, device)
+    G_all = _training_matrix(adata_sp, adata_sp[:, genes], genes, device)
+    if not _all_genes_expressed(S_all) or not _all_genes_expressed(G_all):
+        raise ValueError("Genes with all zero values detected. Run `pp_adatas()`.")
+    S_all, G_all = _to_device(S_all, device), _to_device(G_all, device)
+
+    d_source = None
+    if isinstance(density_prior, str) and density_prior == "rna_count_based":
+        density_prior = adata_sp.obs["rna_count_based_density"]
+    elif isinstance(density_prior, str) and density_prior == "uniform":
+        density_prior = adata_sp.obs["uniform_density"]
+    d = density_prior
+    if mode == "clusters":
+        d_source = np.array(adata_src.obs["cluster_density"])
+    if mode in ["clusters", "constrained"]:
+        if density_prior is None:
+            d = adata_sp.obs["uniform_density"]
+        if lambda_d is None or lambda_d == 0:
+            lambda_d = 1
+
+    def builder(train_genes):
+        idx = torch.as_tensor([pos[g] for g in train_genes], device=device, dtype=torch.long)
+
+        def build():
+            S, G = S_all.index_select(1, idx).contiguous(), G_all.index_select(1, idx).contiguous()
+            if mode == "constrained":
+                return mo.MapperConstrained(S=S, G=G, d=d, device=device, random_state=random_state, gemm_precision=gemm_precision,
+                                            lambda_d=lambda_d, lambda_g1=lambda_g1, lambda_g2=lambda_g2, lambda_r=lambda_r,
+                                            lambda_count=lambda_count, lambda_f_reg=lambda_f_reg, target_count=target_count)
+            return mo.Mapper(S=S, G=G, d=d, device=device, random_state=random_state, gemm_precision=gemm_precision,
+                             lambda_d=lambda_d, lambda_g1=lambda_g1, lambda_g2=lambda_g2, lambda_r=lambda_r, d_source=d_source)
+        return build
+
+    # ---- sparsity columns of compare_spatial_geneexp (:413, :443-449)
+    annotate_gene_sparsity(adata_sp)
+    annotate_gene_sparsity(adata_src)
+    sparsity_sp = adata_sp[:, genes].var["sparsity"]
+    sparsity_sc = adata_src[:, genes].var["sparsity"]
+
+    test_genes_list, test_pred_list, test_score_list, train_score_list, test_df_list = [], [], [], [], []
+    step = max(1, int(folds_per_launch))
+    for g0 in range(0, len(folds), step):
+        group = folds[g0:g0 + step]
+        results, mappers = train_many([builder(tr) for tr, _ in group], num_epochs, learning_rate, device=str(device))
+        for k, ((train_genes, test_genes), res, mapper) in enumerate(zip(group, results, mappers)):
+            tidx = torch.as_tensor([pos[g] for g in test_genes], device=device, dtype=torch.long)
+            S_test, G_test = S_all.index_select(1, tidx).contiguous(), G_all.index_select(1, tidx)
+            # project_genes on the fold's genes (:596-598; constrained: adata_map.X is the unfiltered mapping), held-out columns only
+            pred = mapper.project_genes_device(S_test, unfiltered=True) if mode == "constrained" else mapper.project_genes_device(S_test)
+            pred = pred.to(torch.float32)
+            score = ((pred * G_test).sum(dim=0) / (torch.linalg.norm(pred, dim=0) * torch.linalg.norm(G_test, dim=0))).cpu().numpy()
+            mapper.release()
+            df = pd.DataFrame({"score": score.astype(np.float64), "is_training": False}, index=test_genes)
+            df["sparsity_sp"] = sparsity_sp.loc[test_genes]
+            df["sparsity_sc"] = sparsity_sc.loc[test_genes]
+            df["sparsity_diff"] = df["sparsity_sp"] - df["sparsity_sc"]
+            df = df.sort_values(by="score", ascending=False)
+            test_score = df["score"].mean()
+            train_score = float(list(res[-1]["main_loss"])[-1])
+            if cv_mode == "loo" and return_gene_pred:
+                test_pred_list.append(pred.t().cpu().numpy())            # genes x spots, like adata_ge[:, test_genes].X.T (:602)
+            test_genes_list.append(test_genes)
+            test_score_list.append(test_score)
+            train_score_list.append(train_score)
+            test_df_list.append(df)
+            if verbose is True:
+                print("cv set: {}----train score: {:.3f}----test score: {:.3f}".format(g0 + k + 1, train_score, test_score))
+
+    avg_test_score = np.nanmean(test_score_list)
+    avg_train_score = np.nanmean(train_score_list)
+    cv_dict = {"avg_test_score": avg_test_score, "avg_train_score": avg_train_score}
+    print("cv avg test score {:.3f}".format(avg_test_score))
+    print("cv avg train score {:.3f}".format(avg_train_score))
+    if cv_mode == "loo" and return_gene_pred:
+        test_gene_df = pd.concat(test_df_list, axis=0)
+        adata_ge_cv = make_result_anndata(np.squeeze(test_pred_list).T, adata_sp.obs.copy(),
+                                          pd.DataFrame(test_score_list, columns=["test_score"], index=np.squeeze(test_genes_list)))
+        return cv_dict, adata_ge_cv, test_gene_df
+    return cv_dict

@@ -651,3 +651,24 @@ def test_map_cells_to_space_sparse_input_on_gpu():
         ad_sp2 = AnnDataLite(sp.csr_matrix(ad_sp2.X), obs=ad_sp2.obs, var=ad_sp2.var, uns=ad_sp2.uns)
         sparse = tg.map_cells_to_space(ad_sc2, ad_sp2, mode=mode, device=DEV, num_epochs=8, random_state=42, verbose=False, **kw)
         np.testing.assert_allclose(sparse.X, dense.X, atol=2e-6, err_msg=mode)
+
+
+def test_cross_val_batched_on_gpu():
+    """`cross_val` (reference tangram/utils.py:503-668) in clusters mode, leave-one-out over 11 genes in batches of 4 folds per
+    launch, against the same folds mapped one after the other with `map_cells_to_space(cv_train_genes=...)` and scored on the host."""
+    import tangram_amd as tg
+    from tests.test_map_cells_to_space import _adatas
+    ad_sc, ad_sp = _adatas(C=300, K=11, V=700, seed=4)
+    kw = dict(cluster_label="subclass_label", random_state=7, density_prior="rna_count_based")
+    src = tg.adata_to_cluster_expression(ad_sc, "subclass_label", True, device=DEV)
+    t_ref, tr_ref = [], []
+    for train_genes, test_genes in tg.cv_data_gen(ad_sc, ad_sp, "loo"):
+        ad_map = tg.map_cells_to_space(ad_sc, ad_sp, cv_train_genes=train_genes, mode="clusters", device=DEV, num_epochs=40, verbose=False, **kw)
+        pred = ad_map.X.T.astype(np.float64) @ np.asarray(src[:, test_genes].X, dtype=np.float64)
+        g = np.asarray(ad_sp[:, test_genes].X, dtype=np.float64)
+        t_ref.append(float(((pred * g).sum(0) / (np.linalg.norm(pred, axis=0) * np.linalg.norm(g, axis=0))).mean()))
+        tr_ref.append(float(list(ad_map.uns["training_history"]["main_loss"])[-1]))
+    cv, ad_ge, df = tg.cross_val(ad_sc, ad_sp, mode="clusters", num_epochs=40, device=DEV, return_gene_pred=True, folds_per_launch=4, **kw)
+    assert abs(cv["avg_train_score"] - np.mean(tr_ref)) < 1e-7            # the folds' trainings are the same bits
+    np.testing.assert_allclose(ad_ge.var["test_score"].to_numpy(), t_ref, atol=5e-6)
+    assert ad_ge.X.shape == (700, 11) and len(df) == 11
