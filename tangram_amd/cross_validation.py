@@ -77,13 +77,18 @@ def cross_val(
     *,
     gemm_precision="bf16x3",
     folds_per_launch=16,
+    distributed=False,
+    group=None,
 ):
     """Executes cross validation; arguments and returns as the reference (tangram/utils.py:503-668):
     `cv_dict` {'avg_test_score', 'avg_train_score'} and, with `return_gene_pred` in 'loo' mode, `adata_ge_cv` (the held-out
     genes' predicted spatial expression, spots x genes, `var['test_score']`) and `test_gene_df` ('score', 'is_training',
     'sparsity_sp', 'sparsity_sc', 'sparsity_diff').
 
-    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer), `folds_per_launch`: folds trained together (tg_batch)."""
+    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer); `folds_per_launch`: folds trained together (tg_batch);
+    `distributed=True` (+ optional `group`): the folds are dealt out over the ranks of an initialised torch.distributed process
+    group -- fold i to rank i mod world, every rank on its own `device`, no communication while training -- and the per-fold
+    results are exchanged once at the end: the same call on every rank, every rank returns the full result."""
     # ---- the argument handling of map_cells_to_space (mapping_utils.py:205-229, :280-307), once for all folds
     if lambda_g1 == 0:
         raise ValueError("lambda_g1 cannot be 0.")
@@ -148,12 +153,20 @@ def cross_val(
     sparsity_sp = adata_sp[:, genes].var["sparsity"]
     sparsity_sc = adata_src[:, genes].var["sparsity"]
 
-    test_genes_list, test_pred_list, test_score_list, train_score_list, test_df_list = [], [], [], [], []
+    rank, world = 0, 1
+    if distributed:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("cross_val(distributed=True) needs an initialised torch.distributed process group")
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = list(range(rank, len(folds), world))                  # this rank's folds
+    records = {}                                                 # fold -> (test_genes, test_score, train_score, df, prediction or None)
     step = max(1, int(folds_per_launch))
-    for g0 in range(0, len(folds), step):
-        group = folds[g0:g0 + step]
-        results, mappers = train_many([builder(tr) for tr, _ in group], num_epochs, learning_rate, device=str(device))
-        for k, ((train_genes, test_genes), res, mapper) in enumerate(zip(group, results, mappers)):
+    for g0 in range(0, len(mine), step):
+        ids = mine[g0:g0 + step]
+        fold_group = [folds[i] for i in ids]
+        results, mappers = train_many([builder(tr) for tr, _ in fold_group], num_epochs, learning_rate, device=str(device))
+        for fold_id, (train_genes, test_genes), res, mapper in zip(ids, fold_group, results, mappers):
             tidx = torch.as_tensor([pos[g] for g in test_genes], device=device, dtype=torch.long)
             S_test, G_test = S_all.index_select(1, tidx).contiguous(), G_all.index_select(1, tidx)
             # project_genes on the fold's genes (:596-598; constrained: adata_map.X is the unfiltered mapping), held-out columns only
@@ -168,20 +181,31 @@ def cross_val(
             df = df.sort_values(by="score", ascending=False)
             test_score = df["score"].mean()
             train_score = float(list(res[-1]["main_loss"])[-1])
-            if cv_mode == "loo" and return_gene_pred:
-                test_pred_list.append(pred.t().cpu().numpy())            # genes x spots, like adata_ge[:, test_genes].X.T (:602)
-            test_genes_list.append(test_genes)
-            test_score_list.append(test_score)
-            train_score_list.append(train_score)
-            test_df_list.append(df)
+            keep_pred = cv_mode == "loo" and return_gene_pred                # genes x spots, like adata_ge[:, test_genes].X.T (:602)
+            records[fold_id] = (test_genes, test_score, train_score, df, pred.t().cpu().numpy() if keep_pred else None)
             if verbose is True:
-                print("cv set: {}----train score: {:.3f}----test score: {:.3f}".format(g0 + k + 1, train_score, test_score))
+                print("cv set: {}----train score: {:.3f}----test score: {:.3f}".format(fold_id + 1, train_score, test_score))
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, records, group=group)
+        records = {k: v for part in parts for k, v in part.items()}
+    test_genes_list, test_pred_list, test_score_list, train_score_list, test_df_list = [], [], [], [], []
+    for i in range(len(folds)):
+        test_genes, test_score, train_score, df, pred = records[i]
+        test_genes_list.append(test_genes)
+        test_score_list.append(test_score)
+        train_score_list.append(train_score)
+        test_df_list.append(df)
+        if pred is not None:
+            test_pred_list.append(pred)
 
     avg_test_score = np.nanmean(test_score_list)
     avg_train_score = np.nanmean(train_score_list)
     cv_dict = {"avg_test_score": avg_test_score, "avg_train_score": avg_train_score}
-    print("cv avg test score {:.3f}".format(avg_test_score))
-    print("cv avg train score {:.3f}".format(avg_train_score))
+    if rank == 0:
+        print("cv avg test score {:.3f}".format(avg_test_score))
+        print("cv avg train score {:.3f}".format(avg_train_score))
     if cv_mode == "loo" and return_gene_pred:
         test_gene_df = pd.concat(test_df_list, axis=0)
         adata_ge_cv = make_result_anndata(np.squeeze(test_pred_list).T, adata_sp.obs.copy(),

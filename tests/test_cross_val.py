@@ -103,3 +103,42 @@ def test_argument_errors_are_those_of_map_cells_to_space(sim):
         tg.cross_val(ad_sc, ad_sp, mode="cells", lambda_d=1, device="cpu")
     with pytest.raises(ValueError, match="target_count"):
         tg.cross_val(ad_sc, ad_sp, mode="constrained", device="cpu")
+
+
+def _cv_worker(rank, world, port, sim_path, outdir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tangram_amd import _capi
+        _capi._install_library_for_tests(sim_path)
+        import tangram_amd as tg
+        ad_sc, ad_sp = _adatas(C=50, K=9, V=33, seed=6)
+        cv, ad_ge, df = tg.cross_val(ad_sc, ad_sp, cluster_label="subclass_label", mode="clusters", num_epochs=5, device="cpu",
+                                     return_gene_pred=True, random_state=2, gemm_precision="fp32", folds_per_launch=3, distributed=True)
+        np.savez(os.path.join(outdir, f"cv_{rank}.npz"), test=cv["avg_test_score"], train=cv["avg_train_score"], X=ad_ge.X,
+                 score=df["score"].to_numpy(), genes=np.array(list(df.index)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_folds_dealt_over_two_ranks_give_the_single_process_result(sim, tmp_path):
+    """f-3 "across GPUs": world-2 gloo run, fold i on rank i mod 2, one all-gather of the per-fold records at the end."""
+    import torch.multiprocessing as mp
+    import tangram_amd as tg
+    from tests.test_sharded_gloo import _free_port
+    mp.spawn(_cv_worker, args=(2, _free_port(), sim, str(tmp_path)), nprocs=2, join=True)
+    z0, z1 = np.load(tmp_path / "cv_0.npz"), np.load(tmp_path / "cv_1.npz")
+    for k in z0.files:
+        np.testing.assert_array_equal(z0[k], z1[k], err_msg=k)
+    ad_sc, ad_sp = _adatas(C=50, K=9, V=33, seed=6)
+    cv, ad_ge, df = tg.cross_val(ad_sc, ad_sp, cluster_label="subclass_label", mode="clusters", num_epochs=5, device="cpu",
+                                 return_gene_pred=True, random_state=2, gemm_precision="fp32", folds_per_launch=3)
+    assert float(z0["test"]) == cv["avg_test_score"] and float(z0["train"]) == cv["avg_train_score"]
+    np.testing.assert_array_equal(z0["X"], ad_ge.X)
+    np.testing.assert_array_equal(z0["score"], df["score"].to_numpy())
+    assert list(z0["genes"]) == list(df.index)
+    with pytest.raises(RuntimeError, match="initialised torch.distributed"):
+        tg.cross_val(ad_sc, ad_sp, cluster_label="subclass_label", device="cpu", distributed=True)
