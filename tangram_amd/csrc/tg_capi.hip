@@ -683,9 +683,9 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     // (genepart [nrb][2][Kp] doubles as scratch: first half |G|^2 partials, second half non-zero counts)
     TG_LAUNCH(tg_prep_g, L.nrb, 1, 256, 4 * TG_RB * 4, m->stream, in->G_dev, L.V, L.K, L.Vr, L.Kp, m->fp(L.o_Gp),
               m->fp(L.o_vnorm2), m->fp(L.o_genepart), m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp);
-    TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream, (const float*)m->fp(L.o_genepart), L.nrb, L.Kp,
+    TG_LAUNCH(tg_colsum_parts, (L.Kp + 63) / 64, 1, 1024, 16 * 64 * 4, m->stream, (const float*)m->fp(L.o_genepart), L.nrb, L.Kp,
               m->fp(L.o_gnorm2), 1.f);
-    TG_LAUNCH(tg_colsum_parts, (L.Kp + 255) / 256, 1, 256, 0, m->stream,
+    TG_LAUNCH(tg_colsum_parts, (L.Kp + 63) / 64, 1, 1024, 16 * 64 * 4, m->stream,
               (const float*)(m->fp(L.o_genepart) + (size_t)L.nrb * L.Kp), L.nrb, L.Kp, m->fp(L.o_gfrac), 1.f / (float)L.V);
     if (cfg->has_density) TG_LAUNCH(tg_vec_sum, 1, 1, 1024, 64, m->stream, (const float*)m->fp(L.o_d), L.V, m->fp(L.o_gnorm2) + L.Kp);
     if ((L.has_nb || L.has_ct || L.has_ac) && (rc = tg_setup_spatial(m, in))) return bail(rc);
