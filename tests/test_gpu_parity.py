@@ -378,6 +378,24 @@ def test_small_cluster_path_against_oracle_fp64(i):
     pc.small_cluster_case("cuda:0", C, K, V, constrained, g2, seed=300 + i, n=4)
 
 
+def test_small_cluster_path_is_bit_reproducible():
+    """No float atomics, fixed reduction orders: two runs of the clusters-mode kernels on the same inputs give the same bits,
+    alone and as elements of a batch (8 folds of the tutorial's cross-validation shape, 30 epochs)."""
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    C, K, V = 18, 250, 9852
+    data = orc.make_synthetic(C, K, V, seed=12)
+    M0 = orc.reference_init_M(C, V, 9)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
+    runs = []
+    for _ in range(2):
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device=DEV, lambdas=lam)
+        h = e.new_history(30)
+        e.step(30, 0.1, h)
+        runs.append((e.result().cpu().numpy(), h.cpu().numpy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+
+
 def test_small_cluster_path_agrees_with_the_gemm_path():
     """The same clusters-mode problem on both paths (tile_size pins the GEMM kernels): 50 epochs, mappings within rounding."""
     from tangram_amd.engine import HipMapperEngine
