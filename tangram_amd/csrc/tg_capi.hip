@@ -126,7 +126,7 @@ struct TgLayout {
     int Vs, Vsr, Vmaxl, sp_shard, nrb_s;
     size_t o_GhatFull, o_Gfull;
     int smallc;                                       // C <= 32 (clusters mode): the iteration runs on tg_sc_forward / tg_sc_backward
-    size_t o_Ssmall, o_Stsmall, o_spotpart;
+    size_t o_Sa, o_Sx, o_spotpart;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
     int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
@@ -272,8 +272,8 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     if (L->smallc) {
         const size_t cm = (size_t)tg_sc_cm(L->C);
         L->o_spotpart = take((size_t)((L->V + TG_SC_SB - 1) / TG_SC_SB) * 2 * 4);
-        L->o_Ssmall = take(cm * L->Kp * 4);                            // Sa
-        L->o_Stsmall = take((size_t)16 * ((cm + 15) / 16) * L->Kp * 4);    // Sx
+        L->o_Sa = take(cm * L->Kp * 4);                               // operand images of S (tg_prep_ssmall)
+        L->o_Sx = take((size_t)16 * ((cm + 15) / 16) * L->Kp * 4);
     }
     if (L->sp_shard) {
         L->o_GhatFull = take((size_t)L->Vsr * L->Kp * 4);
@@ -419,8 +419,8 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     TG_LAUNCH_CK();
     if (L.smallc) {
         const int cm = tg_sc_cm(L.C);
-        TG_LAUNCH(tg_prep_ssmall, (16 * ((cm + 15) / 16) * L.Kp + 255) / 256, 1, 256, 0, m->stream, in->S_dev, (long long)L.K, a.aug, L.C, cm, L.K, L.Kp, m->fp(L.o_Ssmall),
-                  m->fp(L.o_Stsmall));
+        TG_LAUNCH(tg_prep_ssmall, (16 * ((cm + 15) / 16) * L.Kp + 255) / 256, 1, 256, 0, m->stream, in->S_dev, (long long)L.K, a.aug, L.C, cm, L.K, L.Kp, m->fp(L.o_Sa),
+                  m->fp(L.o_Sx));
         TG_LAUNCH_CK();
     }
     if (L.T == 256) { const int rc = tg_lds_attr<PR, TgGeoSmall>(); if (rc != TG_OK) return rc; }     // (the backward GEMM may run on 128^2 tiles)
@@ -1005,7 +1005,7 @@ static TgSmallArgs tg_small_args(tg_mapper* m, float* hist_row) {
     f.spotpart = m->fp(L.o_spotpart); f.n_spotpart = (L.V + TG_SC_SB - 1) / TG_SC_SB;
     TgSmallArgs a;
     a.M = (const float*)(m->st + L.s_M); a.rmax = m->fp(L.o_rshift); a.rmul = m->fp(L.o_rmul);
-    a.Sa = m->fp(L.o_Ssmall); a.Sx = m->fp(L.o_Stsmall); a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
+    a.Sa = m->fp(L.o_Sa); a.Sx = m->fp(L.o_Sx); a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
     a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat); a.X = m->fp(L.o_X);
     a.C = L.C; a.CM = tg_sc_cm(L.C); a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = (m->cfg.lambda_g2 != 0.f);
     a.fin = f;

@@ -1240,11 +1240,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ac_grad(TgAcArgs a) {
 
 // ----------------------------------------------------------------------------------------------
 // Small-C path (clusters mode: C <= 32 "cells", e.g. 18 clusters x 250 genes x 9 852 spots, the unit of the reference's
-// cross-validation, utils.py:576-600).  With so few rows the matrix cores would multiply mostly padding and the iteration is bound
-// by its passes over the spot x gene matrices (Ghat partials, Ghat, dGhat image: ~80 MB per iteration at that shape).  Here the
-// contraction over the C clusters is 18 FMAs per element, so Ghat is RECOMPUTED where it is needed instead of stored:
+// cross-validation, utils.py:576-600).  With so few rows the 128- / 256-wide GEMM tiles multiply mostly padding and the iteration
+// is bound by its passes over the spot x gene matrices (Ghat partials, Ghat, dGhat image: ~80 MB per iteration at that shape).
+// Here the contraction over the C clusters is 18 multiply-adds per element, so Ghat is RECOMPUTED where it is needed, not stored:
 //   tg_sc_forward   per block of 64 spots x 256 genes, a wave per 64 genes: Ghat^T tiles (16 genes x 16 spots) on the matrix cores in
-//                   exact fp32 (v_mfma_f32_16x16x4_f32; P from M in registers, S from L2), G through an LDS transpose (one read
+//                   exact fp32 (v_mfma_f32_16x16x4_f32; P from M through LDS, S from pre-laid-out operand images), G through an LDS transpose (one read
 //                   of G), per-gene cosine partials, the density column, optionally the per-spot sums
 //   tg_sc_backward  the same Ghat^T tiles again, dGhat = (alpha_k + va_v) G + (beta_k + vb_v) Ghat (second read of G) in the
 //                   accumulator registers, which ARE the B operand of X_cv += sum_k S_ck dGhat_vk: no dGhat tile, no softmax image
@@ -1252,14 +1252,14 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ac_grad(TgAcArgs a) {
 // the handle (documented in DESIGN.md).  tg_gene_reduce, tg_adam_rowpass (+ the filter kernels) complete the iteration unchanged.
 // ----------------------------------------------------------------------------------------------
 #define TG_SC_MAXC 32
-#define TG_SC_SB 64            // spots per block: lane l of every wave works on spot l of the block
+#define TG_SC_SB 64            // spots per block: four spot tiles of 16
 #define TG_SC_KC 256           // genes per block and chunk: 64 per wave ...
 #define TG_SC_KS 32            // ... staged through LDS 32 at a time
 #define TG_SC_TILE (TG_SC_KS * TG_SC_SB)          // floats of one wave's G sub-tile, [gene quad][spot][4]
 struct TgSmallArgs {
     const float* M; const float* rmax; const float* rmul;    // logits [C][Vp]; forward row constants (P f = exp2((M - max) log2e) * rmul)
     const float* Sa;           // S (with the augmentation column K, zero for c >= C and beyond K) in the operand layouts of the kernels,
-    const float* Sx;           //   one contiguous run per (64 genes, lane): tg_prep_ssmall
+    const float* Sx;           //   one contiguous run per (64 genes, lane): tg_prep_ssmall, tg_sc_load_ops
     const float* G;            // [Vr][Kp] fp32, zero padded
     float* Ghat;               // [Vr][Kp]: only the density column K is written (colsum_v)
     float* genepart;           // [spot blocks][2][Kp]
