@@ -104,6 +104,13 @@ def test_batched_folds_emulated(sim):
                   tol_loss=1e-5, tol_P=2e-5)
 
 
+def test_batched_folds_in_groups_emulated(sim):
+    """From 8 mappings on tg_batch steps 2 - 4 groups of mappings (on streams of their own on the GPU): the per-group argument
+    offsets, 9 Mapper folds as 4 + 5 and 13 MapperConstrained folds as 4 + 4 + 5."""
+    check_batched("cpu", "fp32", C=9, K=12, V=66, B=9, epochs=4, lam=dict(lambda_d=1, lambda_g1=1, lambda_g2=0.5), tol_loss=1e-5, tol_P=2e-5)
+    check_batched_constrained("cpu", "fp32", C=40, K=16, V=50, B=13, epochs=3, tol_loss=1e-5, tol_P=2e-5)
+
+
 def test_batch_rejects_mixed_shapes(sim):
     import ctypes as ct
     import tangram_amd.mapping_optimizer as mo
