@@ -194,7 +194,7 @@ int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_de
  * (result, project, state); they must share the stream they were created on and stay at the same step.  Results are the bits of
  * stepping each handle alone.  Handles of ONE class (all Mapper or all MapperConstrained), without spatial terms, rows <= 16 384 spots.
  * history_dev: host array of B device pointers (one history buffer per mapping) or NULL.
- * From 8 handles on, a batch steps 2 - 4 groups of its handles side by side: group 0 on the handles' stream, the others on
+ * A batch steps its handles as 2 - 4 groups side by side: group 0 on the handles' stream, the others on
  * streams the batch creates (hipStreamNonBlocking; destroyed by tg_batch_destroy).  Every tg_batch_step forks them from the
  * handles' stream when it starts and joins them before it returns, so to the caller everything still happens on that stream. */
 typedef struct tg_batch tg_batch;

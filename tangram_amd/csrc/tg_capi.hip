@@ -1127,20 +1127,23 @@ static int tg_one_step_pipelined(tg_mapper* m, float lr, float* hist_row, bool f
 // ---- batched independent mappings ------------------------------------------------------------------------------
 // B handles of ONE shape and configuration (cross-validation folds, seeds: utils.py:576-600, mapping_parameter_tuning.py:109-131)
 // advance together: one launch per kernel with blockIdx.z = mapping, the per-mapping kernel arguments in device arrays.
+#define TG_BATCH_MAX_GROUPS 4
+// groups a batch of n handles is stepped in (measured at 18 x 250 x 9 852, us per iteration of the whole batch, one group -> this rule:
+// n = 2: 41.8 -> 37.9, 3: 45.3 -> 44.3, 4: 58.8 -> 50.7, 6: 70.1 -> 61.5, 8: 84.5 -> 69.4, 16: 148.6 -> 125; eight groups lose)
+static int tg_batch_groups(int n) { return n <= 3 ? n : std::min((int)TG_BATCH_MAX_GROUPS, (n + 1) / 2); }
 struct tg_batch {
     std::vector<tg_mapper*> h;
     unsigned char* dev;                              // caller-provided scratch: the argument arrays
     size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, o_filt, o_merge, o_scr, o_small, total;
     std::vector<float*> hist;                        // history base pointers the argument arrays currently hold
     bool args_valid;
-    // From 8 mappings on the batch is stepped as 2 - 4 groups, group 0 on the handles' stream and the others on streams the batch
+    // A batch of two or more mappings is stepped as 2 - 4 groups, group 0 on the handles' stream and the others on streams the batch
     // owns (forked from / joined to the handles' stream inside every tg_batch_step call): the workgroups of one group's forward
     // kernel fill the gaps of another group's backward kernel (profiles/r03/run12_streams: + 18 - 22 % at 16 - 32 folds).
     int n_groups;
-    tg_stream_t sub[3];
-    tg_event_t e_fork, e_join[3];
+    tg_stream_t sub[TG_BATCH_MAX_GROUPS - 1];
+    tg_event_t e_fork, e_join[TG_BATCH_MAX_GROUPS - 1];
 };
-#define TG_BATCH_GROUP_MIN 4                         // mappings per group at least
 static size_t tg_batch_layout(int n, tg_batch* b) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
@@ -1177,9 +1180,8 @@ extern "C" int tg_batch_create(tg_mapper* const* mappers, int n, void* scratch_d
     b->dev = (unsigned char*)scratch_dev;
     tg_batch_layout(n, b);
     b->args_valid = false;
-    b->n_groups = std::max(1, std::min(4, n / TG_BATCH_GROUP_MIN));
-    if (n < 2 * TG_BATCH_GROUP_MIN) b->n_groups = 1;
-    for (int g = 0; g < 3; ++g) { b->sub[g] = nullptr; b->e_join[g] = tg_event_t(); }
+    b->n_groups = tg_batch_groups(n);
+    for (int g = 0; g + 1 < TG_BATCH_MAX_GROUPS; ++g) { b->sub[g] = nullptr; b->e_join[g] = tg_event_t(); }
     b->e_fork = tg_event_t();
     if (b->n_groups > 1) {
         bool ok = tg_event_create(&b->e_fork) == 0;
