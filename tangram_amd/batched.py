@@ -10,9 +10,10 @@ Clusters-mode problems are tiny (18 x 250 x 9852) and launch-bound on a 256-CU G
 per-mapping kernel arguments into device arrays and adds a batch index to the grid of every kernel of the iteration
 (blockIdx.z = mapping).  Results are the bits of training the same mappings one by one: nothing is shared between them.
 `Mapper`s batch with `Mapper`s, `MapperConstrained`s with `MapperConstrained`s (utils.py:576-600 passes any `mode`).
-Mappings that cannot be batched (a shape of their own, spatial terms, more than 16 384 spots, `val_each`, or
-a group the C library refuses) are trained by one host thread per mapping (the C ABI releases the GIL; different handles may be
-driven from different threads); `batched=False` additionally gives every mapping a HIP stream of its own.
+Mappings that are not batched (a shape of their own, spatial terms, more than 16 384 spots, more than 2^25 cells x spots -- one
+such mapping fills the GPU and a batch of them measured slower than one after the other --, `val_each`, or a group the C library
+refuses) are trained by one host thread per mapping (the C ABI releases the GIL; different handles may be driven from different
+threads); `batched=False` additionally gives every mapping a HIP stream of its own.
 """
 from __future__ import annotations
 
@@ -65,6 +66,9 @@ class MapperBatch:
 
 
 ROWPASS_MAX_SPOTS = 16384          # TG_ROWPASS_MAX_V (tg_capi.hip): rows the single-kernel update holds in registers
+BATCH_MAX_ELEMENTS = 1 << 25       # cells x spots above which ONE mapping fills the GPU: batching then LOSES (measured, B = 2 - 4 vs one
+                                   # after the other: 4 200 x 1 100: 1.4 - 1.75x, 8 000 x 3 000: 1.05 - 1.13x, 12 000 x 5 000: 0.96 - 0.98x,
+                                   # 26 431 x 9 852: 0.83 - 0.85x; profiles/r03/run15_batch_sizes)
 EMIT_MAX_GENE_COLS = 6128          # (2 Kp + 32) floats of dynamic LDS <= 48 KB in tg_dghat_emit<SELF>
 
 
@@ -76,6 +80,8 @@ def _batch_key(m):
         return None
     c = e.cfg
     if c.lambda_neighborhood_g1 or c.lambda_ct_islands or c.lambda_getis_ord or c.lambda_moran or c.lambda_geary:
+        return None
+    if e.C * e.V > BATCH_MAX_ELEMENTS:
         return None
     if e.V > ROWPASS_MAX_SPOTS or e.K + 1 + 256 > EMIT_MAX_GENE_COLS or c.pipeline_bands > 1:
         return None

@@ -124,3 +124,20 @@ def test_batch_rejects_mixed_shapes(sim):
         MapperBatch([m1, m2])
     with pytest.raises(ValueError, match="twice"):
         MapperBatch([m1, m1])
+
+
+def test_mappings_that_fill_the_gpu_are_not_batched():
+    """train_many's grouping key: above 2^25 cells x spots a batch measured slower than one mapping after the other."""
+    from types import SimpleNamespace
+    from tangram_amd import batched
+
+    class Mapper:                                    # (the key looks at the class NAME and the engine's geometry only)
+        def __init__(self, C, V):
+            cfg = SimpleNamespace(lambda_neighborhood_g1=0, lambda_ct_islands=0, lambda_getis_ord=0, lambda_moran=0, lambda_geary=0,
+                                  pipeline_bands=0, lambda_r=0, lambda_l1=0, lambda_l2=0, beta1=0.9, beta2=0.999, tile_size=0, fwd_splits=0)
+            self._engine = SimpleNamespace(C=C, K=249, V=V, cfg=cfg, precision="bf16x3", device="cuda:0", _torch_stream=None)
+            self._sharded = None
+
+    assert batched._batch_key(Mapper(18, 9852)) is not None and batched._batch_key(Mapper(4200, 1100)) is not None
+    assert batched._batch_key(Mapper(8000, 4000)) is not None                     # 32.0 M <= 2^25
+    assert batched._batch_key(Mapper(26431, 9852)) is None and batched._batch_key(Mapper(30000, 10000)) is None
