@@ -20,6 +20,7 @@ import torch
 from . import mapping_optimizer as mo
 from .anndata_lite import make_result_anndata
 from .batched import train_many
+from .host_rng import legacy_normal_f32
 from .mapping_utils import (_all_genes_expressed, _training_matrix, adata_to_cluster_expression, annotate_gene_sparsity)
 
 
@@ -142,11 +143,10 @@ def cross_val(
         np.random.seed(seed=random_state)
         n_src, n_sp = int(S_all.shape[0]), int(G_all.shape[0])
         if mode == "constrained":
-            np.random.normal(0, 1, (n_src, n_sp))                                          # (:475, discarded by :485)
-            init = dict(M_init=np.random.normal(0, 1, (n_src, n_sp)).astype(np.float32),
-                        F_init=np.random.normal(0, 1, n_src).astype(np.float32))
+            legacy_normal_f32((n_src, n_sp), discard=True)                                 # (:475, discarded by :485)
+            init = dict(M_init=legacy_normal_f32((n_src, n_sp)), F_init=np.random.normal(0, 1, n_src).astype(np.float32))
         else:
-            init = dict(M_init=np.random.normal(0, 1, (n_src, n_sp)).astype(np.float32))
+            init = dict(M_init=legacy_normal_f32((n_src, n_sp)))
 
     def builder(train_genes):
         idx = torch.as_tensor([pos[g] for g in train_genes], device=device, dtype=torch.long)

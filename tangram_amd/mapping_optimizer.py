@@ -35,6 +35,7 @@ import logging
 import numpy as np
 import torch
 
+from .host_rng import legacy_normal_f32
 from . import _capi
 from .engine import HipMapperEngine
 
@@ -186,7 +187,7 @@ class Mapper:
                 seed = _shared_seed(group, self.device)
             if seed:                                         # reference :148-150 (seed 0 / None => unseeded)
                 np.random.seed(seed=seed)
-            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)
+            M_init = legacy_normal_f32((S.shape[0], G.shape[0]))     # np.random.normal(0, 1, ...) bit for bit (host_rng.py)
         self._sharded = None
         if sharded:
             from .sharded import make_sharded
@@ -319,8 +320,8 @@ class MapperConstrained:
                 seed = _shared_seed(group, self.device)
             if seed:                                                                       # :473-474
                 np.random.seed(seed=seed)
-            np.random.normal(0, 1, (S.shape[0], G.shape[0]))                               # :475 (first draw is discarded by :485)
-            M_init = np.random.normal(0, 1, (S.shape[0], G.shape[0])).astype(np.float32)   # :485
+            legacy_normal_f32((S.shape[0], G.shape[0]), discard=True)                      # :475 (first draw is discarded by :485)
+            M_init = legacy_normal_f32((S.shape[0], G.shape[0]))                           # :485
             F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)                 # :490
         self._sharded = None
         if sharded:
