@@ -78,12 +78,21 @@ static inline void cand_xy(const uint32_t* w, int64_t c, double* x1, double* x2,
     *r2 = (*x1) * (*x1) + (*x2) * (*x2);
 }
 
-#define CHUNK_CAND (1 << 22)                 /* candidates per chunk: 16 M words = 64 MB */
+#ifndef CHUNK_CAND
+#define CHUNK_CAND (1 << 18)                 /* candidates per chunk: 1 M words = 4 MB per thread */
+#define ROUND_CHUNKS 4096                    /* chunks per round: 2.5 KB of snapshot each (tests build tiny values of both) */
+#endif
 #define MAX_THREADS 256
+
+typedef struct { uint32_t key[MT_N]; int pos; } mt_snap;
 
 /* out[0 .. n): n draws of legacy normal(0, 1) as float32 (what `.astype(np.float32)` gives); the generator state
  * (key[624], *pos, *has_gauss, *gauss) is read and left exactly as NumPy would leave it.  out == NULL: draws discarded.
- * returns 0, or -1 when out of memory. */
+ * returns 0, or -1 when out of memory.
+ * Rounds of up to a few thousand chunks: (0) one thread walks the generator over the round and keeps its state at every chunk
+ * start (twists only: 0.3 ns per word); (A) all threads, chunk by chunk: the chunk's words from its snapshot, accepted candidates
+ * counted; prefix sum; (B) the words again, the accepted candidates transformed and written where the sequential loop would have
+ * put them.  The generator is finally set to the snapshot of the last chunk used plus the words the reference would have consumed. */
 int tg_legacy_normal_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, float* out, int64_t n, int n_threads) {
     int64_t i = 0;
     if (n <= 0) return 0;
@@ -94,68 +103,82 @@ int tg_legacy_normal_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss,
     }
     const int64_t rest = n - i, pairs = (rest + 1) / 2;          /* accepted candidates still needed; an odd rest caches one value */
     if (pairs == 0) return 0;
-    uint32_t* w = (uint32_t*)malloc((size_t)CHUNK_CAND * 4 * sizeof(uint32_t));
-    if (!w) return -1;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > MAX_THREADS) n_threads = MAX_THREADS;
+    const int64_t max_chunks = ROUND_CHUNKS;
+    mt_snap* snap = (mt_snap*)malloc((size_t)max_chunks * sizeof(mt_snap));
+    int64_t* cnt = (int64_t*)malloc((size_t)(max_chunks + 1) * sizeof(int64_t));
+    uint32_t* wbuf = (uint32_t*)malloc((size_t)n_threads * CHUNK_CAND * 4 * sizeof(uint32_t));
+    if (!snap || !cnt || !wbuf) { free(snap); free(cnt); free(wbuf); return -1; }
     int64_t done = 0;                                            /* accepted so far */
     while (done < pairs) {
-        int64_t cand = (int64_t)((double)(pairs - done) * 1.2733 * 1.02) + 4096;     /* acceptance rate pi / 4 */
-        if (cand > CHUNK_CAND) cand = CHUNK_CAND;
-        uint32_t key0[MT_N];
-        int pos0 = *pos;
-        memcpy(key0, key, sizeof(key0));
-        mt_words(key, pos, w, 4 * cand);
-        int64_t count[MAX_THREADS + 1];
-        int64_t last_c = -1;                                     /* the last candidate the reference would have consumed */
-        int T = n_threads, nt_used = 1;
-        if (cand < 65536) T = 1;
-        count[0] = 0;
+        int64_t cand_total = (int64_t)((double)(pairs - done) * 1.2733 * 1.002) + 8192;      /* acceptance rate pi / 4 */
+        int64_t nch = (cand_total + CHUNK_CAND - 1) / CHUNK_CAND, last_cand = cand_total - (nch - 1) * (int64_t)CHUNK_CAND;
+        if (nch > max_chunks) { nch = max_chunks; last_cand = CHUNK_CAND; }       /* (a full round; the rest follows in the next one) */
+        for (int64_t c = 0; c < nch; c++) {                      /* (0) */
+            memcpy(snap[c].key, key, sizeof(snap[c].key));
+            snap[c].pos = *pos;
+            mt_skip(key, pos, 4 * (c == nch - 1 ? last_cand : (int64_t)CHUNK_CAND));
+        }
+        int T = n_threads;
+        if (cand_total < 65536 && CHUNK_CAND >= 65536) T = 1;
 #ifdef _OPENMP
-#pragma omp parallel num_threads(T)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T)
 #endif
-        {
+        for (int64_t c = 0; c < nch; c++) {                      /* (A) */
 #ifdef _OPENMP
-            const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+            uint32_t* w = wbuf + (size_t)omp_get_thread_num() * CHUNK_CAND * 4;
 #else
-            const int tid = 0, nt = 1;
+            uint32_t* w = wbuf;
 #endif
-            const int64_t c0 = cand * tid / nt, c1 = cand * (tid + 1) / nt;
+            const int64_t nc = c == nch - 1 ? last_cand : (int64_t)CHUNK_CAND;
+            mt_snap st = snap[c];
+            mt_words(st.key, &st.pos, w, 4 * nc);
             int64_t acc = 0;
-            for (int64_t c = c0; c < c1; c++) {
+            for (int64_t k = 0; k < nc; k++) {
                 double x1, x2, r2;
-                cand_xy(w, c, &x1, &x2, &r2);
+                cand_xy(w, k, &x1, &x2, &r2);
                 acc += !(r2 >= 1.0 || r2 == 0.0);
             }
-            count[tid + 1] = acc;
+            cnt[c + 1] = acc;
+        }
+        cnt[0] = 0;
+        for (int64_t c = 0; c < nch; c++) cnt[c + 1] += cnt[c];
+        int64_t end_chunk = -1, end_cand = -1;                   /* where the reference's loop stops, if inside this round */
 #ifdef _OPENMP
-#pragma omp barrier
-#pragma omp single
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T)
 #endif
-            { for (int t = 0; t < nt; t++) count[t + 1] += count[t]; nt_used = nt; }
-            /* (implicit barrier after single) */
-            int64_t k = done + count[tid];                       /* global index of this thread's first accepted candidate */
-            for (int64_t c = c0; c < c1 && k < pairs; c++) {
+        for (int64_t c = 0; c < nch; c++) {                      /* (B) */
+            int64_t k = done + cnt[c];                           /* global index of the chunk's first accepted candidate */
+            if (k >= pairs) continue;
+#ifdef _OPENMP
+            uint32_t* w = wbuf + (size_t)omp_get_thread_num() * CHUNK_CAND * 4;
+#else
+            uint32_t* w = wbuf;
+#endif
+            const int64_t nc = c == nch - 1 ? last_cand : (int64_t)CHUNK_CAND;
+            mt_snap st = snap[c];
+            mt_words(st.key, &st.pos, w, 4 * nc);
+            for (int64_t q = 0; q < nc && k < pairs; q++) {
                 double x1, x2, r2;
-                cand_xy(w, c, &x1, &x2, &r2);
+                cand_xy(w, q, &x1, &x2, &r2);
                 if (r2 >= 1.0 || r2 == 0.0) continue;
                 const double f = sqrt(-2.0 * log(r2) / r2);
                 const int64_t o = i + 2 * k;
                 if (out) out[o] = (float)(f * x2);               /* legacy_gauss returns f * x2 first and keeps f * x1 */
                 if (o + 1 < n) { if (out) out[o + 1] = (float)(f * x1); }
-                else { *has_gauss = 1; *gauss = f * x1; }        /* (only the one thread that owns the last pair gets here) */
-                if (k == pairs - 1) last_c = c;
+                else { *has_gauss = 1; *gauss = f * x1; }        /* (only the one chunk that owns the last pair gets here) */
+                if (k == pairs - 1) { end_chunk = c; end_cand = q; }
                 k++;
             }
         }
-        const int64_t accepted = count[nt_used];
-        if (done + accepted >= pairs) {                          /* finished inside this chunk: rewind to the words really consumed */
-            memcpy(key, key0, sizeof(key0));
-            *pos = pos0;
-            mt_skip(key, pos, 4 * (last_c + 1));
+        if (done + cnt[nch] >= pairs) {                          /* finished inside this round: rewind to the words really consumed */
+            memcpy(key, snap[end_chunk].key, sizeof(snap[end_chunk].key));
+            *pos = snap[end_chunk].pos;
+            mt_skip(key, pos, 4 * (end_cand + 1));
             done = pairs;
-        } else done += accepted;
+        } else done += cnt[nch];
     }
-    free(w);
+    free(snap); free(cnt); free(wbuf);
     return 0;
 }

@@ -63,3 +63,30 @@ def test_mapper_initialisation_is_the_references(helper):
     F2 = np.random.normal(0, 1, C).astype(np.float32)
     Mo, Fo = orc.reference_init_MF_constrained(C, V, 5)
     assert np.array_equal(M2, Mo) and np.array_equal(F2, Fo)
+
+
+def test_many_rounds_and_ragged_chunks(helper, tmp_path):
+    """The chunk / round bookkeeping with tiny chunks (1 024 candidates) and two chunks per round: hundreds of rounds, the stream
+    ending in the middle of a chunk -- same bits, same generator state."""
+    import ctypes as ct
+    import shutil
+    import subprocess
+    so = str(tmp_path / "rng_tiny.so")
+    subprocess.run([shutil.which("gcc"), "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-DCHUNK_CAND=1024",
+                    "-DROUND_CHUNKS=2", host_rng.SRC, "-o", so, "-lm"], check=True)
+    lib = ct.CDLL(so)
+    lib.tg_legacy_normal_f32.restype = ct.c_int
+    lib.tg_legacy_normal_f32.argtypes = host_rng._load().tg_legacy_normal_f32.argtypes
+    for seed, n, cached in ((3, 1, 0), (3, 2047, 1), (8, 100001, 0), (8, 262144, 1), (11, 777777, 0)):
+        np.random.seed(seed)
+        for _ in range(cached):
+            np.random.normal()
+        name, key, pos, hg, cg = np.random.get_state()
+        ref = np.random.normal(0, 1, n).astype(np.float32)
+        st_ref = np.random.get_state()
+        key = key.copy()
+        c_pos, c_has, c_g = ct.c_int(int(pos)), ct.c_int(int(hg)), ct.c_double(float(cg))
+        out = np.empty(n, np.float32)
+        assert lib.tg_legacy_normal_f32(key.ctypes.data, ct.byref(c_pos), ct.byref(c_has), ct.byref(c_g), out.ctypes.data, n, 5) == 0
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (seed, n, cached)
+        assert np.array_equal(key, st_ref[1]) and (c_pos.value, c_has.value, c_g.value) == st_ref[2:], (seed, n, cached)
