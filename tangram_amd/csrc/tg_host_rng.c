@@ -108,6 +108,10 @@ int tg_legacy_normal_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss,
     const int64_t max_chunks = ROUND_CHUNKS;
     mt_snap* snap = (mt_snap*)malloc((size_t)max_chunks * sizeof(mt_snap));
     int64_t* cnt = (int64_t*)malloc((size_t)(max_chunks + 1) * sizeof(int64_t));
+    {                                                            /* no more threads (and word buffers) than chunks */
+        const int64_t all_chunks = ((int64_t)((double)pairs * 1.2733 * 1.002) + 8192 + CHUNK_CAND - 1) / CHUNK_CAND;
+        if (all_chunks < n_threads) n_threads = (int)all_chunks;
+    }
     uint32_t* wbuf = (uint32_t*)malloc((size_t)n_threads * CHUNK_CAND * 4 * sizeof(uint32_t));
     if (!snap || !cnt || !wbuf) { free(snap); free(cnt); free(wbuf); return -1; }
     int64_t done = 0;                                            /* accepted so far */

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "tg_host_rng.c")
 OUT = os.path.join(HERE, "csrc", "libtangram_host.so")
-MIN_VALUES = 1 << 16                     # below this NumPy is as fast
+MIN_VALUES = 1 << 20                     # below this NumPy is as fast (10 ms)
 _lib = None
 _tried = False
 
