@@ -269,9 +269,9 @@ static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
     // small-C path (tg_kernels.h): single GPU, rows within the one-kernel update, no spatial terms (their extra gradient rides dGhat)
     L->smallc = (L->C <= TG_SC_MAXC && !spatial && !L->sp_shard && cfg->n_ranks == 0 && L->Vtot == L->V && L->bands == 1 &&
                  L->V <= TG_ROWPASS_MAX_V && cfg->tile_size == 0) ? 1 : 0;
+    L->o_spotpart = take((size_t)L->nrb * 2 * 4);               // per-block sums of the spots' loss terms (32- or 64-spot blocks)
     if (L->smallc) {
         const size_t cm = (size_t)tg_sc_cm(L->C);
-        L->o_spotpart = take((size_t)((L->V + TG_SC_SB - 1) / TG_SC_SB) * 2 * 4);
         L->o_Sa = take(cm * L->Kp * 4);                               // operand images of S (tg_prep_ssmall)
         L->o_Sx = take((size_t)16 * ((cm + 15) / 16) * L->Kp * 4);
     }
@@ -785,13 +785,19 @@ static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
     TG_LAUNCH(tg_ghat_reduce, nrb, (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS, 256, 4 * 64 * 2 * 16, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
-    TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
-              m->fp(L.o_genestat));
+    if (nrb > 512) {              // many row blocks, e.g. clusters mode on 50 000 spots: 16 genes x 64 groups per workgroup
+        TG_LAUNCH(tg_gene_reduce_tall, (L.Kp + 15) / 16, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
+                  m->fp(L.o_genestat));
+    } else {
+        TG_LAUNCH(tg_gene_reduce, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
+                  m->fp(L.o_genestat));
+    }
     tg_prof_mark(m, "tg_gene_reduce");
     return TG_OK;
 }
 
 // arguments of the loss / gradient-coefficient stage: the statistics -> coefficient map (f) and the dGhat emitter (e)
+static bool tg_emit_self_ok(const tg_mapper* m);
 static void tg_loss_args(tg_mapper* m, float* hist_row, TgFinalizeArgs& f, TgEmitArgs& e) {
     const TgLayout& L = m->L;
     f.genestat = m->fp(L.o_genestat); f.gnorm2 = m->fp(L.o_gnorm2); f.Ghat = m->fp(L.o_Ghat);
@@ -808,6 +814,7 @@ static void tg_loss_args(tg_mapper* m, float* hist_row, TgFinalizeArgs& f, TgEmi
     f.lambda_nb = m->cfg.lambda_neighborhood_g1; f.lambda_ct = m->cfg.lambda_ct_islands; f.T = L.T_ct;
     f.part_out = m->comm ? m->fp(L.o_rowpair) + 2 * (size_t)L.C : nullptr;       // spot shard: this rank's parts of the spot sums
     f.spotpart = nullptr; f.n_spotpart = 0;
+    if (tg_emit_self_ok(m)) { f.spotpart = m->fp(L.o_spotpart); f.n_spotpart = (L.V + TG_RB - 1) / TG_RB; }     // (tg_dghat_emit<SELF> leaves them)
     e.Ghat = m->fp(L.o_Ghat); e.G = m->fp(L.o_Gp); e.coef = m->fp(L.o_coef); e.vcoef = m->fp(L.o_vcoef);
     e.dG = m->ws + L.o_dG;
     // (spot shard: the extra gradient is evaluated for ALL spots; this handle's rows start at its spot offset)
@@ -901,7 +908,7 @@ static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1) {
     TgRowsumArgs r;
     r.part = m->fp(L.o_part); r.nvt = L.Vr / L.bwd_T; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
     r.c_begin = c0; r.c_end = c1;
-    TG_LAUNCH(tg_rowsum_parts, (c1 - c0 + 255) / 256, 1, 256, 0, stream, r);
+    TG_LAUNCH(tg_rowsum_parts, (c1 - c0 + 15) / 16, 1, 256, 16 * 16 * 4, stream, r);
 }
 
 static void tg_launch_hist_regs(tg_mapper* m, tg_stream_t stream, float* hist_row) {
@@ -987,7 +994,9 @@ static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t s
         if (whole) tg_prof_mark(m, "tg_adam_rowpass");
         return TG_OK;
     }
-#define TG_AUGO(F, X) TG_LAUNCH((tg_adam_update<F, X, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u)
+    const bool few = (c1 - c0) <= 64 && L.V > 4096;      // a handful of long rows: 1 024 threads per cell
+#define TG_AUGO(F, X) do { if (few) TG_LAUNCH((tg_adam_update<F, X, true, 1024>), c1 - c0 + extra_wg, 1, 1024, 512, stream, u); \
+                           else TG_LAUNCH((tg_adam_update<F, X, true>), c1 - c0 + extra_wg, 1, 256, 128, stream, u); } while (0)
     if (L.full) { if (x16) TG_AUGO(true, true); else TG_AUGO(true, false); }
     else { if (x16) TG_AUGO(false, true); else TG_AUGO(false, false); }
 #undef TG_AUGO

@@ -483,34 +483,37 @@ TG_DEV void tg_ghat_reduce_body(const TgGhatReduceArgs& a) {
     }
 }
 
-// K2b: second stage of the per-gene sums (fixed order => deterministic): 64 genes x 16 partial groups per block.
-// (A latency-bound kernel: every thread walks nrb / 16 row blocks; with 4 groups it took 29 us at 600 row blocks.)
+// K2b: second stage of the per-gene sums (fixed order => deterministic): KX genes x 1024 / KX partial groups per block.
+// (A latency-bound kernel: every thread walks nrb / groups row blocks; with 4 groups it took 29 us at 600 row blocks.  KX = 64:
+//  16 groups; KX = 16, for more than 512 row blocks: 64 groups and four times the workgroups -- 36 -> 12 us at 1 563 row blocks.)
 #define TG_GR_GROUPS 16
+template <int KX>
 TG_DEV void tg_gene_reduce_body(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
+    constexpr int NG = 1024 / KX;
     TG_LDS_DECL;
-    float* red = (float*)tg_lds;        // [TG_GR_GROUPS][64][2]
-    const int kx = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + kx;
+    float* red = (float*)tg_lds;        // [NG][KX][2]
+    const int kx = threadIdx.x % KX, grp = threadIdx.x / KX;
+    const int k = blockIdx.x * KX + kx;
     float d0 = 0.f, n0 = 0.f, d1 = 0.f, n1 = 0.f;
     if (k < Kp) {
         int b = grp;
-        for (; b + TG_GR_GROUPS < nrb; b += 2 * TG_GR_GROUPS) {
+        for (; b + NG < nrb; b += 2 * NG) {
             d0 += genepart[((size_t)b * 2 + 0) * Kp + k];
             n0 += genepart[((size_t)b * 2 + 1) * Kp + k];
-            d1 += genepart[((size_t)(b + TG_GR_GROUPS) * 2 + 0) * Kp + k];
-            n1 += genepart[((size_t)(b + TG_GR_GROUPS) * 2 + 1) * Kp + k];
+            d1 += genepart[((size_t)(b + NG) * 2 + 0) * Kp + k];
+            n1 += genepart[((size_t)(b + NG) * 2 + 1) * Kp + k];
         }
-        for (; b < nrb; b += TG_GR_GROUPS) {
+        for (; b < nrb; b += NG) {
             d0 += genepart[((size_t)b * 2 + 0) * Kp + k];
             n0 += genepart[((size_t)b * 2 + 1) * Kp + k];
         }
     }
-    red[(grp * 64 + kx) * 2 + 0] = d0 + d1;
-    red[(grp * 64 + kx) * 2 + 1] = n0 + n1;
+    red[(grp * KX + kx) * 2 + 0] = d0 + d1;
+    red[(grp * KX + kx) * 2 + 1] = n0 + n1;
     __syncthreads();
     if (grp == 0 && k < Kp) {
         float d = 0.f, n = 0.f;
-        for (int g = 0; g < TG_GR_GROUPS; ++g) { d += red[(g * 64 + kx) * 2 + 0]; n += red[(g * 64 + kx) * 2 + 1]; }
+        for (int g = 0; g < NG; ++g) { d += red[(g * KX + kx) * 2 + 0]; n += red[(g * KX + kx) * 2 + 1]; }
         genestat[k] = d;
         genestat[Kp + k] = n;
     }
@@ -549,8 +552,8 @@ struct TgFinalizeArgs {
     int V_sp;                  // spots the spatial sums (ct islands) run over: V, or ALL spots on a spot shard (the spatial terms are
                                // evaluated on the gathered Ghat there, identically on every rank)
     float* part_out;           // spot shards: [0] = this rank's part of the voxel score (sum_v cos / V_total), [1] = of the KL sum; or null
-    float* spotpart; int n_spotpart;     // clusters-mode kernels: [blocks of 64 spots][2] sums of the per-spot (cosine, KL) terms, left by
-                                         // tg_sc_backward (which evaluates tg_spot_coef anyway); null: tg_loss_scalars walks the spots itself
+    float* spotpart; int n_spotpart;     // [spot blocks][2] sums of the per-spot (cosine, KL) terms, left by the kernel that evaluates
+                                         // tg_spot_coef anyway (tg_sc_backward, tg_dghat_emit<SELF>); null: tg_loss_scalars walks the spots itself
 };
 
 TG_DEV float tg_block_sum_1024(float x, float* red) {
@@ -727,17 +730,23 @@ TG_DEV void tg_dghat_emit_body(const TgEmitArgs& a) {
             if (k < a.K) tg_gene_coef(a.fin, a.fin.genestat, a.fin.gnorm2, a.fin.lambda_g1, k, al, be, c);
             cf[k] = al; cf[a.Kp + k] = be;
         }
+        float c_blk = 0.f, kl_blk = 0.f;
         if (threadIdx.x < TG_RB) {
             const int v = vbeg + threadIdx.x;
-            float va = 0.f, vb = 0.f, av = 0.f, c = 0.f, kl = 0.f;
+            float va = 0.f, vb = 0.f, av = 0.f;
             if (v < a.V) {
                 float dot, n2a, n2b, colsum, dv;
                 tg_spot_stats_load(a.fin, v, dot, n2a, n2b, colsum, dv);
                 const float rho_scale = a.fin.fsum_dev ? 1.f / a.fin.fsum_dev[0] : a.fin.rho_scale;
-                tg_spot_coef(a.fin, dot, n2a, n2b, colsum, dv, rho_scale, va, vb, av, c, kl);
+                tg_spot_coef(a.fin, dot, n2a, n2b, colsum, dv, rho_scale, va, vb, av, c_blk, kl_blk);
             }
             cf[2 * a.Kp + threadIdx.x] = va; cf[2 * a.Kp + TG_RB + threadIdx.x] = vb;
             if (v < a.Vr) { a.fin.vcoef[v] = va; a.fin.vcoef[a.Vr + v] = vb; a.fin.vcoef[2 * a.Vr + v] = av; }   // a_v: read by the backward / update kernels
+        }
+        if (threadIdx.x < 64 && a.fin.spotpart) {        // the spots' loss terms summed per block: the history workgroup adds the blocks up
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { c_blk += tg_shfl_xor(c_blk, m); kl_blk += tg_shfl_xor(kl_blk, m); }
+            if (threadIdx.x == 0) { a.fin.spotpart[2 * blockIdx.x] = c_blk; a.fin.spotpart[2 * blockIdx.x + 1] = kl_blk; }
         }
         __syncthreads();
         coef = cf;
@@ -1602,10 +1611,13 @@ struct TgUpdateArgs {
     TgFinalizeArgs fin;                               //    (tg_loss_scalars; see tg_dghat_emit<SELF>)
 };
 
-template <bool FULL, bool X16, bool STREAM>
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
+// NT = 256 threads per cell; 1 024 for a handful of long rows (clusters mode beyond 16 384 spots: with 18 workgroups the kernel is
+// one dependent chain of V / (4 NT) trips per thread -- 81 us at 50 000 spots with 256 threads)
+template <bool FULL, bool X16, bool STREAM, int NT = 256>
+TG_KERNEL void TG_LAUNCH_BOUNDS(NT) tg_adam_update(TgUpdateArgs a) {
+    constexpr int NW = NT / 64;
     TG_LDS_DECL;
-    float* red = (float*)tg_lds;          // [4 waves][2]  (history workgroup: [4][5])
+    float* red = (float*)tg_lds;          // [NW waves][2]  (history workgroup: [NW][5])
     if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
     const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float sh = a.rshift[c], iz = a.rinvz[c], rc = a.r[c];
@@ -1614,7 +1626,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
     const size_t row = (size_t)c * a.Vp;
     float lmax = TG_NEG_BIG, lsum = 0.f;
-    for (int v = 4 * t; v < a.V; v += 1024) {
+    for (int v = 4 * t; v < a.V; v += 4 * NT) {
         f32x4 xq;
         if constexpr (X16) {
             const u32x2 xp = tg_ld_stream<STREAM>((const u32x2*)((const unsigned short*)a.X + row + v));
@@ -1657,7 +1669,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
         lsum = lsum * tg_exp(lmax - nmx) + qs;
         lmax = nmx;
     }
-    // (max, sum exp) of the whole new row: wave shuffle tree, then the 4 waves through LDS (fixed order)
+    // (max, sum exp) of the whole new row: wave shuffle tree, then the waves through LDS (fixed order)
 #pragma unroll
     for (int msk = 1; msk <= 32; msk <<= 1) {
         const float om = tg_shfl_xor(lmax, msk), os = tg_shfl_xor(lsum, msk);
@@ -1668,9 +1680,10 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_update(TgUpdateArgs a) {
     if (lane == 0) { red[wave * 2] = lmax; red[wave * 2 + 1] = lsum; }
     __syncthreads();
     if (t == 0) {
-        float mx = tg_fmax(tg_fmax(red[0], red[2]), tg_fmax(red[4], red[6]));
+        float mx = red[0];
+        for (int w = 1; w < NW; ++w) mx = tg_fmax(mx, red[w * 2]);
         float z = 0.f;
-        for (int w = 0; w < 4; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
+        for (int w = 0; w < NW; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
         a.pair_out[c] = mx;
         a.pair_out[a.C + c] = z;
         if (a.finalize) {
@@ -1857,13 +1870,24 @@ struct TgRowsumArgs {
     float* rowq;               // [np][C] summed partials (row 0 = r_c)
     int c_begin, c_end;        // cells handled by this launch
 };
+// 16 cells x 16 groups of spot tiles per workgroup: a cell's partials p = g, g + 16, ... side by side, then the groups in fixed order
+// (one thread per cell walking all V / 128 partials took 61 us at 50 000 spots and 18 rows of M)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
-    const int c = a.c_begin + blockIdx.x * 256 + threadIdx.x;
-    if (c >= a.c_end) return;
+    TG_LDS_DECL;
+    float* red = (float*)tg_lds;                                 // [16][16]
+    const int r = threadIdx.x & 15, g = threadIdx.x >> 4, c = a.c_begin + blockIdx.x * 16 + r;
     for (int q = 0; q < a.np; ++q) {
         float s = 0.f;
-        for (int p = 0; p < a.nvt; ++p) s += a.part[((size_t)p * a.np + q) * a.C + c];
-        a.rowq[(size_t)q * a.C + c] = s;
+        if (c < a.c_end)
+            for (int p = g; p < a.nvt; p += 16) s += a.part[((size_t)p * a.np + q) * a.C + c];
+        red[g * 16 + r] = s;
+        __syncthreads();
+        if (g == 0 && c < a.c_end) {
+            float t = 0.f;
+            for (int i = 0; i < 16; ++i) t += red[i * 16 + r];
+            a.rowq[(size_t)q * a.C + c] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -1908,10 +1932,11 @@ template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd
 }
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) { tg_ghat_reduce_body(a); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce_b(const TgGhatReduceArgs* argv) { tg_ghat_reduce_body(argv[blockIdx.z]); }
-TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body(genepart, nrb, Kp, genestat); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body<64>(genepart, nrb, Kp, genestat); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_tall(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body<16>(genepart, nrb, Kp, genestat); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_b(const TgGeneReduceArgs* argv) {
     const TgGeneReduceArgs a = argv[blockIdx.z];
-    tg_gene_reduce_body(a.genepart, a.nrb, a.Kp, a.genestat);
+    tg_gene_reduce_body<64>(a.genepart, a.nrb, a.Kp, a.genestat);
 }
 template <class PR, bool EXTRA, bool SELF> TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit(TgEmitArgs a) { tg_dghat_emit_body<PR, EXTRA, SELF>(a); }
 template <class PR> TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_dghat_emit_b(const TgEmitArgs* argv) { tg_dghat_emit_body<PR, false, true>(argv[blockIdx.z]); }

@@ -191,9 +191,11 @@ def test_pipelined_schedule_matches_sequential(precision):
     assert np.abs(outs[0][0] - outs[1][0]).max() < (1e-4 if precision != "bf16" else 5e-3)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 4), (5, 1, 7), (3, 2, 1), (1, 4, 6), (17, 130, 9), (18, 250, 9852), (70000, 8, 70)])
+@pytest.mark.parametrize("shape", [(2, 3, 4), (5, 1, 7), (3, 2, 1), (1, 4, 6), (17, 130, 9), (18, 250, 9852), (70000, 8, 70),
+                                   (18, 60, 20000), (5, 8, 70000)])
 def test_degenerate_and_extreme_shapes(shape):
-    """Single cell / gene / spot, a clusters-mode shape (18 x 250 x 9852) and a tall shape (grid limits)."""
+    """Single cell / gene / spot, a clusters-mode shape (18 x 250 x 9852), a tall shape (grid limits) and clusters mode on
+    rows beyond the one-kernel update (the long-row path on a handful of rows: 1 024-thread `tg_adam_update`, `tg_gene_reduce_tall`)."""
     from oracle import tangram_oracle as orc
     from tangram_amd.engine import HipMapperEngine
     from tangram_amd import _capi
