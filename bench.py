@@ -58,6 +58,43 @@ def kernel_model(name, C, K, V):
     return None, None
 
 
+def bench_folds(device, folds=16, steps=300):
+    """leave-one-gene-out folds of the tutorial's clusters-mode problem (18 clusters x 250 genes x 9 852 spots,
+    utils.py:576-600) -- stepping rate of one fold alone and of `folds` folds advanced together (tg_batch)."""
+    import torch
+    import tangram_amd.mapping_optimizer as mo
+    from tangram_amd.batched import MapperBatch
+    from tangram_amd.synthetic import make_workload
+    C, K, V = 18, 250, 9852
+    w = make_workload(C, K + folds, V, device, seed=1)
+    ds = torch.full((C,), 1.0 / C, device=device)
+
+    def fold(i):
+        keep = torch.tensor([g for g in range(K + folds) if g != i][:K], device=device)
+        return mo.Mapper(S=w["S"][:, keep].contiguous(), G=w["G"][:, keep].contiguous(), d=w["d"], d_source=ds, lambda_d=1, device=device,
+                         random_state=i + 1)
+
+    def rate(step, n):
+        step(50)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        step(steps)
+        torch.cuda.synchronize(device)
+        return n * steps / (time.perf_counter() - t0)
+
+    m1 = fold(0)
+    one = rate(lambda k: m1._engine.step(k, 0.1), 1)
+    m1.release()
+    ms = [fold(i) for i in range(folds)]
+    b = MapperBatch(ms)
+    many = rate(lambda k: b.step(k, 0.1), folds)
+    b.close()
+    for m in ms:
+        m.release()
+    return {"workload": f"{C} clusters x {K} genes x {V} spots, mode='clusters' folds of a leave-one-gene-out cross-validation",
+            "one_fold_iters_per_s": one, "folds_per_launch": folds, "fold_iters_per_s": many, "unit": "mapping iterations/s summed over the folds"}
+
+
 def csrc_sha():
     """Fingerprint of the kernel sources (tangram_amd/csrc/*): PMC tables are only valid for the kernels they were collected on."""
     import hashlib
@@ -327,6 +364,12 @@ def main():
             del e2, run2
             torch.cuda.empty_cache()
     del w
+    next_rows = {}
+    if world == 1 and not args.no_alt and args.workload == "cfg2" and not args.shape:
+        try:        # SURVEY 8(f-3) beside the headline (never `value`): clusters-mode cross-validation folds, one alone and 16 per tg_batch
+            next_rows["f3_batched_mappings"] = bench_folds(device)
+        except Exception as e:
+            next_rows["f3_batched_mappings"] = {"error": repr(e)}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -377,6 +420,7 @@ def main():
             "kernels_pass": {"schedule": "sequential (one stream, HIP event after every kernel)", "steps": nprof,
                              "ms_per_step": 1e3 * seq_elapsed / nprof, "value": nprof / seq_elapsed},
             "alt_precisions": alt,
+            "next_rows": next_rows,
         }
         if world == 1 and not args.no_cpu_baseline:
             if args.workload == "cfg4":
