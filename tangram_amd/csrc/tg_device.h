@@ -53,6 +53,8 @@ TG_DEV f32x4 tg_mma_f32(float a, float b, f32x4 c) {
 TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
     memcpy(lds_wave_base + 16 * hipsim::lane_id(), src, 16);
 }
+TG_DEV void tg_glds16_uncounted(const unsigned char* src, unsigned char* lds_wave_base) { tg_glds16(src, lds_wave_base); }
+TG_DEV void tg_dma_drain() {}
 #else
 // ------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
@@ -97,6 +99,20 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same copy issued from an asm statement, i.e. OUTSIDE hipcc's wait-count bookkeeping.  hipcc books the builtin as a
+// flat access that may touch LDS, and from then on every wait it inserts for a ds_read is lgkmcnt(0) -- in the GEMM main
+// loops: a full LDS drain in front of every MFMA group instead of the counted lgkmcnt(2 - 3) it emits without a copy in
+// flight (cdna_hip_programming.md section 5.7).  The price: nothing waits for these copies but tg_dma_drain().
+TG_DEV void tg_glds16_uncounted(const unsigned char* src, unsigned char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+// vmcnt(0) as the BUILTIN (simm16 0x0F70 = vmcnt 0, expcnt 7, lgkmcnt 15): hipcc keeps a user wait as it is and books it, so
+// its own vector loads count as complete afterwards (an asm wait would leave them pending on some paths of its scoreboard,
+// and the next write to one of their registers then gets a vmcnt(0) of its own in the middle of the MFMA stream).
+TG_DEV void tg_dma_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 #endif
 
 TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }

@@ -158,6 +158,8 @@ struct TgMmaShape {
 // wave instruction is lane-linear (64 x 16 B = 8 tile rows), so the XOR swizzle is applied to the per-lane SOURCE
 // address (logical chunk = physical chunk ^ swizzle(row)), the read side applies the same involution.
 // (`part` of `nparts`: the copies i = part, part + nparts, ... only -- for spreading the issue over the MFMA groups)
+// The copies are issued outside hipcc's wait counters (tg_glds16_uncounted): the caller drains them with tg_dma_drain()
+// in front of the barrier that publishes the tile.
 template <int ROWS, int NT>
 TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, u32x4* tile, int t, int wave,
                          int part = 0, int nparts = 1) {
@@ -166,7 +168,7 @@ TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_by
         if (i % nparts != part) continue;
         const int idx = t + i * NT, row = idx >> 3;
         const int logical = tg_swz(row, idx & 7);                 // involution: logical = physical ^ s(row)
-        tg_glds16(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
+        tg_glds16_uncounted(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
     }
 }
 
@@ -379,6 +381,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
         load_stage(s_begin);
         store_stage(lds);
         if (early && s_begin + 1 < s_end) load_stage(s_begin + 1);
+        tg_dma_drain();
         __syncthreads();
         for (int s = s_begin; s < s_end; ++s) {
             u32x4* cur = lds + ((s - s_begin) & 1) * GE::STAGE_CHUNKS;
@@ -395,6 +398,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
                 tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [](int) {});
             }
             if (!early && more) store_stage(nxt);
+            tg_dma_drain();
             __syncthreads();
         }
     }
@@ -826,23 +830,27 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
         const size_t pitch = (size_t)nsteps * 128;
         tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, 0, lds, t, wave);
         tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, 0, lds + GE::A_CHUNKS, t, wave);
+        tg_dma_drain();
         __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
+        // The last step is peeled off the loop: inside the loop the DMA issue is unconditional, so a step is ONE basic block
+        // (a `more` test per MFMA group made four, and hipcc then waits lgkmcnt(0) at the head of every block).
+        for (int s = 0; s + 1 < nsteps; ++s) {
             u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
-            const bool more = (s + 1) < nsteps;     // DMA of the next step lands while the matrix cores run, issued a few
-            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [&](int i) {     // copies per MFMA group (see tg_tile_mma)
+            tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [&](int i) {     // DMA of the next step lands while the matrix cores run,
                 constexpr int NG_B = TgMmaShape<PR, GE>::NG, NSP = (NG_B * 3) / 4 > 0 ? (NG_B * 3) / 4 : 1, NIT = GE::LA + GE::LB;
-                if (!more) return;
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
+                for (int k = 0; k < NIT; ++k) {                          // issued a few copies per MFMA group (see tg_tile_mma)
                     if ((k * NSP) / NIT != i) continue;
                     if (k < GE::LA) tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, (size_t)(s + 1), nxt, t, wave, k, GE::LA);
                     else tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave, k - GE::LA, GE::LB);
                 }
             });
-            __syncthreads();                        // drains the DMA (vmcnt) and releases `cur` for the step after next
+            tg_dma_drain();
+            __syncthreads();                        // publishes the next tile and releases `cur` for the step after next
         }
+        tg_tile_mma<PR, GE>(lds + ((nsteps - 1) & 1) * GE::STAGE_CHUNKS, wm, wn, lane, acc, [](int) {});
+        __syncthreads();
     }
 
     // ---------------- epilogue ----------------
