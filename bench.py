@@ -105,6 +105,13 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+# scripts/probes/gemm_loop_lab.hip on MI355X (profiles/r04/lab): the backward GEMM's tile set with the matrix-core instructions
+# ONLY (operands held in registers, no LDS read, no copy, no barrier).  With split-bf16 random operands the chip clocks to its
+# power budget (~2.1 GHz shader clock under this load, s_memtime), so the matrix pipes themselves need this long:
+MFMA_ONLY_PROBE = {"bf16x3": {"ms_per_gemm": 0.90, "frac_of_dense_peak": 0.84, "effective_clock_GHz": 2.1,
+                              "source": "profiles/r04/lab/lab.txt (VAR 1), cfg2 backward tile set incl. padding"}}
+
+
 def pmc_traffic(precision):
     """(HBM bytes per launch, note) from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE).  The table carries the fingerprint of the
@@ -386,7 +393,10 @@ def main():
             run2(n2)
             torch.cuda.synchronize(device)
             dt = (time.perf_counter() - t1) / n2
-            alt[prec] = {"value": 1.0 / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt, "steps": n2, "dtype": DTYPE_NAME[prec]}
+            alt[prec] = {"value": 1.0 / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt, "steps": n2, "dtype": DTYPE_NAME[prec],
+                         "roofline": dict(roof_of(24.0 * C * V + 8.0 * (C * K + V * K), 4.0 * C * V * K, dt, prec),
+                                          scope="one iteration", hbm_frac=(24.0 * C * V + 8.0 * (C * K + V * K)) / dt / HBM_PEAK,
+                                          mfma_frac=4.0 * C * V * K / dt / MFMA_PEAK[prec])}
             e2.release()
             del e2, run2
             torch.cuda.empty_cache()
@@ -427,6 +437,30 @@ def main():
         roof["hbm_frac_of_measured_copy_bw"] = bytes_alg * its / HBM_COPY / world
         roof["mfma_frac"] = flops_alg * its / MFMA_PEAK[precision] / world
         roof["kernels"] = [dict(name=k["name"], avg_ms=k["avg_ms"], **k["roofline"]) for k in kern if "roofline" in k]
+        # The structural ceiling of this design, on the face of the line.  The step is a CHAIN of two
+        # matrix-core-bound GEMMs and one HBM-bound update (softmax backward needs the complete row dot before any element of
+        # the row may be updated: DESIGN.md section 4), so its floor is the SUM of the three kernels' own roofs, not their
+        # maximum; the north star's 0.60-of-HBM target prices the iteration against the maximum.
+        heavy = {k["name"]: k for k in kern if k["name"] in HEAVY and k.get("launches")}
+        t_seq = sum(k["avg_ms"] for k in heavy.values())
+        t_gemm_roof = 1e3 * (flops_alg / world) / MFMA_PEAK[precision]
+        t_upd_roof = 1e3 * (24.0 * C * V / world) / HBM_PEAK
+        t_bound = 1e3 * max((bytes_alg / world) / HBM_PEAK, (flops_alg / world) / MFMA_PEAK[precision])
+        roof["floor"] = {
+            "sequential_measured_ms": t_seq,
+            "sequential_measured_parts": {n: k["avg_ms"] for n, k in heavy.items()},
+            "sequential_roof_ms": t_gemm_roof + t_upd_roof,
+            "sequential_roof_its": 1e3 / (t_gemm_roof + t_upd_roof),
+            "overlap_bound_ms": t_bound, "overlap_bound_its": 1e3 / t_bound,
+            "mfma_only_probe": MFMA_ONLY_PROBE.get(precision),
+            "note": "sequential_roof = (two GEMMs at the dense MFMA peak of the precision) + (update at 8 TB/s): what the three-kernel "
+                    "chain could reach with every kernel AT its roof; overlap_bound = max(t_MFMA, t_HBM) of the whole iteration, "
+                    "reachable only if the phases overlapped (every overlap design measured slower, DESIGN.md section 6b)"}
+        target_its = 0.60 * HBM_PEAK / (bytes_alg / world)
+        roof["target"] = {"definition": "north_star: >= 0.60 of the HBM roofline (8 TB/s) on the fused iteration",
+                          "its": target_its, "ms_per_step": 1e3 / target_its, "met": bool(its >= target_its),
+                          "frac_of_target": its / target_its,
+                          "reachable_by_this_design": bool(1e3 / (t_gemm_roof + t_upd_roof) >= target_its)}
         metric = ("mapping iterations/s at 30k cells x 1k genes x 10k spots (mode='cells', lambda_g1=1, lambda_d=1)"
                   if args.workload == "cfg2" and not args.shape else
                   f"mapping iterations/s at {C} cells x {K} genes x {V} spots ({wl_desc})")

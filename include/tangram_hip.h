@@ -156,7 +156,10 @@ void tg_mapper_destroy(tg_mapper* m);
  * runs n_steps iterations (loss, backward, Adam) with learning rate lr; writes one history row per step
  * into history_dev[(first_row + i) * TG_H_NTERMS ...] (device memory, may be NULL).
  * Asynchronous on the handle's stream: nothing in it synchronises, times or queries the device, so a call can be captured into a
- * HIP graph from the first step on (the kernel selection is a fixed function of the configuration, tg_config.bwd_tile).  */
+ * HIP graph from the first step on (the kernel selection is a fixed function of the configuration, tg_config.bwd_tile).  What a
+ * captured call bakes into the graph: the step indices it covers (Adam's bias corrections 1 - beta^t are launch arguments
+ * computed on the host) and the history rows it writes -- a replay re-runs exactly those steps, bit for bit, from whatever state
+ * the handle's buffers hold (tests/test_gpu_graph_capture.py replays 50 captured steps from a restored state).  */
 int tg_mapper_step(tg_mapper* m, int n_steps, float lr, float* history_dev, int first_row);
 
 /* Spot-sharded multi-GPU run: attach a communicator to a handle created with n_spots < n_spots_total (collective; performs the
@@ -196,7 +199,13 @@ int tg_csr_columns_to_dense(const int64_t* indptr_dev, const int32_t* indices_de
  * history_dev: host array of B device pointers (one history buffer per mapping) or NULL.
  * A batch steps its handles as 2 - 4 groups side by side: group 0 on the handles' stream, the others on
  * streams the batch creates (hipStreamNonBlocking; destroyed by tg_batch_destroy).  Every tg_batch_step forks them from the
- * handles' stream when it starts and joins them before it returns, so to the caller everything still happens on that stream. */
+ * handles' stream when it starts and joins them before it returns, so to the caller everything still happens on that stream.
+ * tg_batch_step never synchronises: the per-mapping argument arrays are assembled in page-locked host memory the batch owns and
+ * reach `scratch_dev` as one asynchronous copy, re-issued only when `history_dev` holds other pointers than in the previous call.
+ * A call that does not change them is kernel launches + the fork / join events only and can be captured into a HIP graph (a call
+ * that would have to re-upload under capture is refused with TG_ERR_STATE: step the batch once with the same history pointers
+ * first).  As for tg_mapper_step, the Adam bias corrections and the history rows of the captured steps are launch arguments: a
+ * replay repeats exactly the captured step indices (tests/test_gpu_graph_capture.py). */
 typedef struct tg_batch tg_batch;
 size_t tg_batch_query_bytes(int n_mappers);
 int tg_batch_create(tg_mapper* const* mappers, int n_mappers, void* scratch_dev, tg_batch** out);

@@ -50,6 +50,26 @@ def cv_data_gen(adata_sc, adata_sp, cv_mode="loo"):
         yield list(genes[:lo]) + list(genes[hi:]), list(genes[lo:hi])
 
 
+from contextlib import nullcontext as _nullcontext
+
+from .batched import BATCH_MAX_ELEMENTS
+
+
+def _folds_resident(requested, n_src, n_sp, n_genes, device):
+    """How many folds' mappers may be RESIDENT at once.  `train_many` builds every mapper of a group before it trains any; a
+    mapper holds its logits, both Adam moments, the backward product and the GEMM workspace (~6 x cells x spots x 4 B, plus the
+    operand images of its genes).  The reference trains one fold at a time (utils.py:576-600), so a problem that fits there must
+    fit here: above the size where one mapping fills the GPU (`batched.BATCH_MAX_ELEMENTS`: such folds are not batched anyway)
+    the folds run one by one; below it the group is capped by the free device memory."""
+    if n_src * n_sp > BATCH_MAX_ELEMENTS:
+        return 1
+    per_fold = 6 * 4 * n_src * (n_sp + 64) + 3 * 4 * (n_src + n_sp + 512) * (n_genes + 512)
+    if device.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(device)
+        return max(1, min(requested, int(0.6 * free // per_fold)))
+    return requested
+
+
 def _to_device(x, device):
     return (x if torch.is_tensor(x) else torch.as_tensor(np.ascontiguousarray(x))).to(device=device, dtype=torch.float32)
 
@@ -175,7 +195,7 @@ def cross_val(
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = list(range(rank, len(folds), world))                  # this rank's folds
     records = {}                                                 # fold -> (test_genes, test_score, train_score, df, prediction or None)
-    step = max(1, int(folds_per_launch))
+    step = _folds_resident(max(1, int(folds_per_launch)), int(S_all.shape[0]), int(G_all.shape[0]), len(genes), device)
     for g0 in range(0, len(mine), step):
         ids = mine[g0:g0 + step]
         fold_group = [folds[i] for i in ids]
@@ -202,7 +222,10 @@ def cross_val(
     if world > 1:
         import torch.distributed as dist
         parts = [None] * world
-        dist.all_gather_object(parts, records, group=group)
+        # (on the NCCL backend all_gather_object stages through torch.cuda.current_device(), not through `device`: make them agree,
+        #  else every rank of a job that never called torch.cuda.set_device stages on cuda:0)
+        with (torch.cuda.device(device) if device.type == "cuda" else _nullcontext()):
+            dist.all_gather_object(parts, records, group=group)
         records = {k: v for part in parts for k, v in part.items()}
     test_genes_list, test_pred_list, test_score_list, train_score_list, test_df_list = [], [], [], [], []
     for i in range(len(folds)):

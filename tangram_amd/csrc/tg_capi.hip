@@ -35,6 +35,10 @@ static int tg_event_create(tg_event_t* e) { *e = 0; return 0; }
 static void tg_event_destroy(tg_event_t) {}
 static void tg_event_record(tg_event_t, tg_stream_t) {}           // the emulator runs launches synchronously in program order
 static void tg_stream_wait(tg_stream_t, tg_event_t) {}
+static void tg_event_host_wait(tg_event_t) {}
+static void* tg_host_pinned_alloc(size_t n) { return malloc(n); }
+static void tg_host_pinned_free(void* p) { free(p); }
+static bool tg_stream_capturing(tg_stream_t) { return false; }
 #else
 typedef hipStream_t tg_stream_t;
 // Every launch is checked where it is issued: the FIRST failing kernel of a call is remembered by name (thread-local) and
@@ -81,6 +85,14 @@ static int tg_event_create(tg_event_t* e) { return (int)hipEventCreateWithFlags(
 static void tg_event_destroy(tg_event_t e) { if (e) (void)hipEventDestroy(e); }
 static void tg_event_record(tg_event_t e, tg_stream_t s) { (void)hipEventRecord(e, s); }
 static void tg_stream_wait(tg_stream_t s, tg_event_t e) { (void)hipStreamWaitEvent(s, e, 0); }
+static void tg_event_host_wait(tg_event_t e) { (void)hipEventSynchronize(e); }
+// page-locked HOST memory (the library still allocates no device memory): the source of a truly asynchronous, capturable copy
+static void* tg_host_pinned_alloc(size_t n) { void* p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+static void tg_host_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+static bool tg_stream_capturing(tg_stream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
 #endif
 
 // ----------------------------------------------------------------------------------------------
@@ -149,8 +161,23 @@ static int tg_choose_splits(int tiles, int nsteps, int slots, int precision, int
     return best;
 }
 
-static int tg_make_layout(const tg_config* cfg, TgLayout* L) {
-    if (!cfg) return tg_fail(TG_ERR_INVALID, "null config");
+static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
+    if (!cfg_in) return tg_fail(TG_ERR_INVALID, "null config");
+    // Clusters-mode problems (at most TG_SC_MAXC rows of M, one GPU, no spatial terms, tile_size not pinned) TRAIN on the exact-fp32
+    // tg_sc_* kernels whatever gemm precision is configured.  Everything else such a handle does -- tg_mapper_validate,
+    // tg_mapper_project, tg_mapper_project_genes: GEMMs with at most 32 contraction rows, i.e. free -- then runs in exact fp32 too,
+    // so that validation losses and projections come from the same numerical path as the training history (round 3 ran them at
+    // the configured precision).  The EFFECTIVE precision is L->prec; tg_mapper_create stores it back into the handle's config.
+    tg_config cfg_eff = *cfg_in;
+    {
+        const bool spatial0 = cfg_in->lambda_neighborhood_g1 > 0.f || cfg_in->lambda_ct_islands > 0.f || cfg_in->lambda_getis_ord > 0.f ||
+                              cfg_in->lambda_moran > 0.f || cfg_in->lambda_geary > 0.f;
+        const int vtot0 = cfg_in->n_spots_total > 0 ? cfg_in->n_spots_total : cfg_in->n_spots;
+        if (cfg_in->n_cells >= 1 && cfg_in->n_cells <= TG_SC_MAXC && !spatial0 && cfg_in->n_ranks == 0 && vtot0 == cfg_in->n_spots &&
+            cfg_in->n_spots <= TG_ROWPASS_MAX_V && cfg_in->tile_size == 0 && cfg_in->precision >= 0 && cfg_in->precision <= 2)
+            cfg_eff.precision = TG_PREC_F32;
+    }
+    const tg_config* cfg = &cfg_eff;
     if (cfg->abi_version != TG_ABI_VERSION) return tg_fail(TG_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, TG_ABI_VERSION);
     if (cfg->n_cells < 1 || cfg->n_genes < 1 || cfg->n_spots < 1) return tg_fail(TG_ERR_INVALID, "empty problem: C=%d K=%d V=%d", cfg->n_cells, cfg->n_genes, cfg->n_spots);
     if (cfg->precision < 0 || cfg->precision > 2) return tg_fail(TG_ERR_INVALID, "unknown precision %d", cfg->precision);
@@ -650,6 +677,8 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     tg_mapper* m = new (std::nothrow) tg_mapper();
     if (!m) return tg_fail(TG_ERR_INVALID, "out of host memory");
     m->cfg = *cfg; m->L = L;
+    m->cfg.precision = L.prec;                            // the EFFECTIVE precision (tg_make_layout: fp32 for clusters-mode handles)
+    cfg = &m->cfg;
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
     m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->comm = nullptr;
@@ -1146,6 +1175,13 @@ struct tg_batch {
     size_t o_fwd, o_ghat, o_gene, o_emit, o_bwd, o_upd, o_hreg, o_filt, o_merge, o_scr, o_small, total;
     std::vector<float*> hist;                        // history base pointers the argument arrays currently hold
     bool args_valid;
+    // The argument arrays are assembled in page-locked host memory the batch owns and go to the device as ONE asynchronous copy:
+    // tg_batch_step never synchronises the stream (round 3 built them in vectors on the stack and had to wait for the copies
+    // before returning).  `e_upload` marks the last copy out of `stage`; the host waits for it only before REWRITING the staging
+    // area, i.e. when a later call passes other history pointers while that copy is still queued.
+    unsigned char* stage;
+    tg_event_t e_upload;
+    bool upload_pending;
     // A batch of two or more mappings is stepped as 2 - 4 groups, group 0 on the handles' stream and the others on streams the batch
     // owns (forked from / joined to the handles' stream inside every tg_batch_step call): the workgroups of one group's forward
     // kernel fill the gaps of another group's backward kernel (profiles/r03/run12_streams: + 18 - 22 % at 16 - 32 folds).
@@ -1189,6 +1225,10 @@ extern "C" int tg_batch_create(tg_mapper* const* mappers, int n, void* scratch_d
     b->dev = (unsigned char*)scratch_dev;
     tg_batch_layout(n, b);
     b->args_valid = false;
+    b->upload_pending = false;
+    b->e_upload = tg_event_t();
+    b->stage = (unsigned char*)tg_host_pinned_alloc(b->total);
+    if (!b->stage || tg_event_create(&b->e_upload) != 0) { tg_batch_destroy(b); return tg_fail(TG_ERR_HIP, "could not allocate the batch's page-locked argument staging (%zu bytes)", b->total); }
     b->n_groups = tg_batch_groups(n);
     for (int g = 0; g + 1 < TG_BATCH_MAX_GROUPS; ++g) { b->sub[g] = nullptr; b->e_join[g] = tg_event_t(); }
     b->e_fork = tg_event_t();
@@ -1206,15 +1246,27 @@ extern "C" void tg_batch_destroy(tg_batch* b) {
         for (int g = 0; g + 1 < b->n_groups; ++g) { tg_stream_destroy(b->sub[g]); tg_event_destroy(b->e_join[g]); }
         tg_event_destroy(b->e_fork);
     }
+    if (b->upload_pending) tg_event_host_wait(b->e_upload);
+    tg_event_destroy(b->e_upload);
+    tg_host_pinned_free(b->stage);
     delete b;
 }
 
 template <class PR>
 static int tg_batch_upload(tg_batch* b, float* const* hist) {
     const int n = (int)b->h.size();
-    std::vector<TgFwdArgs> fw(n); std::vector<TgGhatReduceArgs> gh(n); std::vector<TgGeneReduceArgs> gr(n);
-    std::vector<TgEmitArgs> em(n); std::vector<TgBwdArgs> bw(n); std::vector<TgUpdateArgs> up(n); std::vector<TgHistRegArgs> hr(n);
-    std::vector<TgFilterArgs> fl(n); std::vector<TgMergeArgs> mg(n); std::vector<float*> scr(n); std::vector<TgSmallArgs> sm(n);
+    tg_stream_t s = b->h[0]->stream;
+    if (tg_stream_capturing(s))
+        return tg_fail(TG_ERR_STATE, "tg_batch_step under stream capture must not change the batch's argument arrays: step the batch once "
+                                     "with the same history pointers before capturing");
+    if (b->upload_pending) { tg_event_host_wait(b->e_upload); b->upload_pending = false; }       // the staging area is about to be rewritten
+    memset(b->stage, 0, b->total);
+    TgFwdArgs* fw = (TgFwdArgs*)(b->stage + b->o_fwd); TgGhatReduceArgs* gh = (TgGhatReduceArgs*)(b->stage + b->o_ghat);
+    TgGeneReduceArgs* gr = (TgGeneReduceArgs*)(b->stage + b->o_gene); TgEmitArgs* em = (TgEmitArgs*)(b->stage + b->o_emit);
+    TgBwdArgs* bw = (TgBwdArgs*)(b->stage + b->o_bwd); TgUpdateArgs* up = (TgUpdateArgs*)(b->stage + b->o_upd);
+    TgHistRegArgs* hr = (TgHistRegArgs*)(b->stage + b->o_hreg); TgFilterArgs* fl = (TgFilterArgs*)(b->stage + b->o_filt);
+    TgMergeArgs* mg = (TgMergeArgs*)(b->stage + b->o_merge); float** scr = (float**)(b->stage + b->o_scr);
+    TgSmallArgs* sm = (TgSmallArgs*)(b->stage + b->o_small);
     const bool constrained = (b->h[0]->cfg.mode == TG_MODE_CONSTRAINED);
     for (int i = 0; i < n; ++i) {
         tg_mapper* m = b->h[i];
@@ -1244,21 +1296,9 @@ static int tg_batch_upload(tg_batch* b, float* const* hist) {
         }
         scr[i] = m->fp(L.o_scal);
     }
-    tg_stream_t s = b->h[0]->stream;
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_fwd, fw.data(), n * sizeof(TgFwdArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_ghat, gh.data(), n * sizeof(TgGhatReduceArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_gene, gr.data(), n * sizeof(TgGeneReduceArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_emit, em.data(), n * sizeof(TgEmitArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_bwd, bw.data(), n * sizeof(TgBwdArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_upd, up.data(), n * sizeof(TgUpdateArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_hreg, hr.data(), n * sizeof(TgHistRegArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_filt, fl.data(), n * sizeof(TgFilterArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_merge, mg.data(), n * sizeof(TgMergeArgs), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_scr, scr.data(), n * sizeof(float*), s));
-    TG_CK(tg_memcpy_h2d(b->dev + b->o_small, sm.data(), n * sizeof(TgSmallArgs), s));
-#ifndef TG_SIM
-    TG_CK(hipStreamSynchronize(s));        // (the host vectors go out of scope; once per tg_batch_step call, not per iteration)
-#endif
+    TG_CK(tg_memcpy_h2d(b->dev, b->stage, b->total, s));          // one copy, asynchronous (page-locked source that outlives the call)
+    tg_event_record(b->e_upload, s);
+    b->upload_pending = true;
     b->hist.assign(n, nullptr);
     for (int i = 0; i < n; ++i) b->hist[i] = hist ? hist[i] : nullptr;
     b->args_valid = true;

@@ -132,6 +132,14 @@ class HipMapperEngine:
                    self.workspace.data_ptr(), self._hip_stream, ct.byref(handle))
         self._h = handle
         self._sync()            # inputs were only borrowed for the duration of create()
+        # The precision the handle really computes in.  Clusters-mode problems (<= 32 rows of M, one GPU, no spatial terms,
+        # tile_size not pinned) train on the library's exact-fp32 clusters-mode kernels whatever `gemm_precision` says, and the
+        # library then also validates / projects such a handle in fp32 (tg_make_layout): `precision` is what was asked for,
+        # `effective_precision` what runs.
+        geo = (ct.c_int * 8)()
+        self.effective_precision = precision
+        if hasattr(self._lib, "tg_debug_layout") and self._lib.tg_debug_layout(ct.byref(cfg), geo) == 0 and geo[7]:
+            self.effective_precision = "fp32"
         self._scratch_row = torch.zeros(_capi.H_NTERMS, dtype=torch.float32, device=self.device)
 
     # -- plumbing ---------------------------------------------------------------------------------

@@ -94,9 +94,10 @@ def project_genes(adata_map, adata_sc, cluster_label=None, scale=True, *, mapper
     if not own:
         # the trained mapper projects through its own seam: on a spot-sharded run that gathers every rank's block of spots
         # (mapper._engine alone is only the LOCAL shard); MapperConstrained: softmax(M) without the filter, like adata_map.X
-        try:
+        from .mapping_optimizer import MapperConstrained
+        if isinstance(mapper, MapperConstrained):
             X_space = mapper.project_genes_device(S_all, unfiltered=True)
-        except TypeError:
+        else:
             X_space = mapper.project_genes_device(S_all)
         X_space = X_space.cpu().numpy()
         adata_ge = _result(X_space, adata_map.var, adata_sc.var, adata_sc.uns)
