@@ -30,9 +30,31 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define TG_LDS_DECL unsigned char* tg_lds = hipsim::M().lds
 #define TG_SCHED_FENCE() ((void)0)
 #define __syncthreads() hipsim::block_barrier()
+#ifdef TG_SIM_HWMATH
+// EXPERIMENT build of the emulator (scripts/exp_rounding_drift.py; never used by the test-suite): the transcendental helpers as
+// the HARDWARE evaluates them -- __expf(x) = v_exp_f32(x * log2(e)) with the product rounded to fp32, __logf(x) =
+// v_log_f32(x) * ln 2, and v_exp_f32 / v_log_f32 themselves as 1-ulp approximations (modelled: the exact value rounded TOWARDS
+// ZERO instead of to nearest) -- to measure how much of the hardware-vs-emulator trajectory difference these roundings explain.
+// (TG_SIM_HWMATH = 1: towards zero; 2: away from zero; 3: one of the two neighbours picked by a hash of the argument -- three
+//  different 1-ulp-accurate "implementations" of the same functions)
+TG_DEV float tg_hw_rtz(double v) {
+    float f = (float)v;
+    if (f == 0.f || !(fabs(v) < 1e38)) return f;
+    const float lo = (fabs((double)f) > fabs(v)) ? nextafterf(f, 0.f) : f;                    // neighbour towards zero
+    const float hi = (fabs((double)lo) < fabs(v)) ? nextafterf(lo, lo > 0.f ? 3e38f : -3e38f) : lo;   // neighbour away from zero
+    if (TG_SIM_HWMATH == 1) return lo;
+    if (TG_SIM_HWMATH == 2) return hi;
+    unsigned long long b; memcpy(&b, &v, 8); b ^= b >> 29; b *= 0x9E3779B97F4A7C15ull; b ^= b >> 32;
+    return (b & 1) ? lo : hi;
+}
+TG_DEV float tg_exp2(float x) { return tg_hw_rtz(exp2((double)x)); }
+TG_DEV float tg_exp(float x) { return tg_exp2(x * 1.4426950408889634f); }
+TG_DEV float tg_log(float x) { return tg_hw_rtz(log2((double)x)) * 0.6931471805599453f; }
+#else
 TG_DEV float tg_exp(float x) { return expf(x); }
 TG_DEV float tg_log(float x) { return logf(x); }
 TG_DEV float tg_exp2(float x) { return exp2f(x); }
+#endif
 TG_DEV float tg_shfl_xor(float v, int mask) { return hipsim::shfl_idx(v, hipsim::lane_id() ^ mask); }
 TG_DEV int tg_lane() { return hipsim::lane_id(); }
 TG_DEV int tg_uniform(int x) { return x; }

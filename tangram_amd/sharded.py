@@ -258,9 +258,14 @@ def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapp
     V = G.shape[0]
     lam = lambdas or {}
     spatial = any(lam.get(k, 0) > 0 for k in ("lambda_neighborhood_g1", "lambda_ct_islands", "lambda_getis_ord", "lambda_moran", "lambda_geary"))
+    # Emptiness is decided for EVERY rank's block, identically on every rank, before anything collective happens: with the
+    # block partition of the spatial terms (ceil(V / world) spots per rank) trailing ranks can end up empty (V = 17 on 8 ranks
+    # leaves ranks 6 and 7 without spots); raising only there would leave the others hanging in the next collective.
+    empty = [r for r in range(world) if shard_bounds(V, world, r, spatial)[1] - shard_bounds(V, world, r, spatial)[0] < 1]
+    if empty:
+        raise ValueError(f"rank(s) {empty} would own no spots (V={V}, world={world}"
+                         + (", blocks of ceil(V / world) spots for the spatial terms" if spatial else "") + ")")
     lo, hi = shard_bounds(V, world, rank, spatial)
-    if hi - lo < 1:
-        raise ValueError(f"rank {rank} would own no spots (V={V}, world={world})")
     G_l = G[lo:hi]
     M_l = M0[:, lo:hi]
     if isinstance(M_l, np.ndarray):

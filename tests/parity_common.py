@@ -18,13 +18,19 @@ TOL = {
 
 
 # The 500-epoch cases of the reference's own test grid are ill-conditioned: the reference's fp32 run drifts from its fp64 run (flat
-# valley).  Beyond the well-conditioned prefix an implementation is held to this multiple of that drift, term by term.
-# Measured: GEMM kernels 1.0 - 2.2 x; the clusters-mode kernels (these cases have 12 clusters) 0.4 - 3.0 x on the GPU and
-# 0.4 - 1.4 x for the SAME kernels on the CPU emulator, which differs from the hardware only in the rounding of exp2 -- where an
-# fp32 run ends inside that multiple is amplified round-off, not a property of the implementation.  The GPU suite runs these cases
-# on BOTH kernel families: clusters-mode kernels against OWN_SPREAD, the GEMM kernels (pinned by `tile_size`) against OWN_SPREAD_GEMM.
+# valley).  Beyond the well-conditioned prefix an implementation is held to this multiple of that drift, term by term and at the end
+# point.  ONE bound for both kernel families (the clusters-mode kernels these 12-cluster cases run on by default, and the GEMM
+# kernels pinned by `tile_size`), because the multiple an fp32 run ends at is amplified round-off of the transcendentals, not a
+# property of a kernel family -- measured (scripts/exp_rounding_drift.py -> profiles/r04/exp_rounding/drift.json): the SAME kernel
+# sources on the CPU emulator, with exp2 / exp / log rounded four different 1-ulp-accurate ways (host libm; towards zero; away from
+# zero; hash-picked neighbour -- the last three also with the hardware's fp32 product x * log2(e) inside exp), end the seven cases at
+#     largest multiple     libm    towards 0    away    hashed        MI355X (v_exp_f32 / v_log_f32)
+#     clusters kernels     1.44      2.49       2.12     1.60          3.0   (round 3, profiles/r03)
+#     GEMM kernels         2.22      1.72       2.74     2.00          2.2
+# i.e. anywhere in 1.4 - 2.7 for either family from a 1-ulp change of three scalar functions; the hardware's 3.0 is one more draw
+# from that distribution.  4 = 1.5 x the largest emulated draw.  (Round 3 carried two constants, 4 for the clusters kernels and 3
+# for the GEMM kernels: a bound fitted per family to one draw each.)
 OWN_SPREAD = 4.0
-OWN_SPREAD_GEMM = 3.0              # the same cases with the GEMM kernels pinned (`tile_size`): round 3's bound for them stands
 
 
 def load_golden(name):

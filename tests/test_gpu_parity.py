@@ -28,7 +28,7 @@ def test_golden_reference_trajectories(name, precision):
     pc.check_against_golden(res, precision, full_length=True)
     if CASES[name][0] <= 32:      # at most 32 cells: the run above took the clusters-mode kernels; the GEMM kernels on the same case
         res = pc.run_case(name, DEV, precision, pin_gemm=True)
-        pc.check_against_golden(res, precision, full_length=True, own_spread=pc.OWN_SPREAD_GEMM)
+        pc.check_against_golden(res, precision, full_length=True)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
