@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
 
 typedef enum tg_status {
     TG_OK = 0,
@@ -223,6 +223,15 @@ int tg_csr_gather_columns(const int64_t* indptr_dev, const int32_t* indices_dev,
  * in double, rounded once; normalize: divided by their total (also double) -> the rna_count_based density prior.               */
 int tg_row_sums(const float* X_dev, int64_t ld, int32_t n_cols, const int64_t* indptr_dev, const float* data_dev, int64_t n_rows,
                 float* out_dev, int32_t normalize, void* hip_stream);
+/* Initial logits generated on the device: out[r][c] (row pitch ld floats) = standard normal of (seed, r * n_cols_total + col0 + c),
+ * r < n_rows, c < n_cols.  Opt-in replacement of `np.random.normal(0, 1, (n_cells, n_spots))` (mapping_optimizer.py:147-157) for
+ * problems whose cells x spots plane must never exist on the host (BASELINE config 4: 40 GB of logits; `Mapper(..., init="device")`).
+ * Counter-based (SplitMix64 finaliser + Box-Muller per element): a spot shard passes its first global spot as `col0` and
+ * generates exactly the columns it owns -- any partition of the spots yields the same logits.  Not NumPy's stream: parity runs
+ * use the reference's generator.  (ABI version 4.) */
+int tg_init_logits_normal(float* out_dev, int64_t n_rows, int64_t n_cols, int64_t ld, uint64_t seed, int64_t col0,
+                          int64_t n_cols_total, void* hip_stream);
+
 /* Replaces the per-cluster `adata[mask].X.sum(axis=0)` / `.mean(axis=0)` loop of adata_to_cluster_expression (mapping_utils.py:126-132):
  * out_dev[c][k] = sum (mean != 0: mean) of X_dev[r][k] over the member rows r of cluster c (member_rows_dev[member_indptr_dev[c] ..
  * member_indptr_dev[c+1])), accumulated in double in member order.                                                              */

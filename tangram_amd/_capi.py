@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtangram_hip.so")      # the in-tree build, nothing else (experiments: scripts/with_lib.py)
 
-TG_ABI_VERSION = 3
+TG_ABI_VERSION = 4
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 H_NTERMS = 16
@@ -84,7 +84,8 @@ def _declare(lib):
     lib.tg_csr_gather_columns.argtypes = [vp, vp, vp, ct.c_int64, vp, i32, vp, ct.c_int64, vp]
     lib.tg_row_sums.argtypes = [vp, ct.c_int64, i32, vp, vp, ct.c_int64, vp, i32, vp]
     lib.tg_cluster_aggregate.argtypes = [vp, ct.c_int64, i32, vp, vp, i32, i32, vp, ct.c_int64, vp]
-    for name in ("tg_csr_gather_columns", "tg_row_sums", "tg_cluster_aggregate"):
+    lib.tg_init_logits_normal.argtypes = [vp, ct.c_int64, ct.c_int64, ct.c_int64, ct.c_uint64, ct.c_int64, ct.c_int64, vp]
+    for name in ("tg_csr_gather_columns", "tg_row_sums", "tg_cluster_aggregate", "tg_init_logits_normal"):
         getattr(lib, name).restype = i32
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
@@ -108,7 +109,7 @@ EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_creat
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
            "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step",
            "tg_mapper_filter_state", "tg_mapper_profile",
-           "tg_mapper_profile_read", "tg_mapper_validate"]
+           "tg_mapper_profile_read", "tg_mapper_validate", "tg_init_logits_normal"]
 
 
 def lib():

@@ -1718,6 +1718,20 @@ extern "C" int tg_row_sums(const float* X_dev, int64_t ld, int32_t n_cols, const
     return TG_OK;
 }
 
+extern "C" int tg_init_logits_normal(float* out_dev, int64_t n_rows, int64_t n_cols, int64_t ld, uint64_t seed, int64_t col0,
+                                     int64_t n_cols_total, void* hip_stream) {
+    if (!out_dev) return tg_fail(TG_ERR_INVALID, "null argument");
+    if (n_rows < 1 || n_cols < 1 || ld < n_cols || col0 < 0 || n_cols_total < col0 + n_cols)
+        return tg_fail(TG_ERR_INVALID, "bad block: %lld x %lld (ld %lld) at column %lld of %lld", (long long)n_rows, (long long)n_cols, (long long)ld,
+                       (long long)col0, (long long)n_cols_total);
+    const long long quads = n_rows * ((n_cols + 3) / 4);
+    const int grid = (int)(quads / 256 + 1 < 16384 ? quads / 256 + 1 : 16384);
+    TG_LAUNCH(tg_init_normal, grid, 1, 256, 0, (tg_stream_t)hip_stream, out_dev, (long long)n_rows, (long long)n_cols, (long long)ld,
+              (unsigned long long)seed, (long long)col0, (long long)n_cols_total);
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
+
 extern "C" int tg_cluster_aggregate(const float* X_dev, int64_t ld, int32_t n_cols, const int32_t* member_indptr_dev,
                                     const int32_t* member_rows_dev, int32_t n_clusters, int32_t mean, float* out_dev, int64_t ld_out,
                                     void* hip_stream) {

@@ -2206,6 +2206,34 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_val_finalize(TgValArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// Initial logits generated ON the device (opt-in replacement of `np.random.normal(0, 1, (n_cells, n_spots))`,
+// mapping_optimizer.py:147-157, for problems whose C x V plane must never exist on the host: cfg4 holds 40 GB of logits).
+// Counter-based: element (cell c, GLOBAL spot v) is a function of (seed, c * n_spots_total + v) alone -- a spot shard generates
+// exactly the columns it owns and any partition of the spots yields the same logits.  One SplitMix64 finaliser per element
+// gives two 32-bit uniforms, Box-Muller (cosine branch) the standard normal.  NOT NumPy's stream: parity runs keep the
+// reference's generator (host_rng.py); SURVEY 7.3-7 allows a device generator where the CPU reference cannot run.
+// ----------------------------------------------------------------------------------------------
+TG_DEV float tg_counter_normal(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + (seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u1 = ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);      // 24 bits: (0, 1), never 0
+    const float u2 = ((float)(unsigned)(z & 0xFFFFFFu) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * tg_log(u1)) * cosf(6.283185307179586f * u2);
+}
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_init_normal(float* out, long long n_rows, long long n_cols, long long ld, unsigned long long seed,
+                                                    long long col0, long long n_cols_total) {
+    const long long quads = (n_cols + 3) / 4, total = n_rows * quads;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const long long r = q / quads, c = 4 * (q % quads);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < n_cols) out[r * ld + c + e] = tg_counter_normal(seed, (unsigned long long)(r * n_cols_total + col0 + c + e));
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // set-up kernels: operand images of S and the padded fp32 copy of G
 // ----------------------------------------------------------------------------------------------
 struct TgPrepSArgs {

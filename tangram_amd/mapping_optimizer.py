@@ -145,9 +145,22 @@ class Mapper:
         M_init=None,
         distributed=False,
         group=None,
+        init="reference",
+        gather_result=True,
     ):
+        """Extra keywords (all opt-in; the defaults are the reference's behaviour):
+        init="device": the initial logits come from the library's counter-based device generator (device_init.py) instead of
+            NumPy's global stream -- seed-reproducible (`random_state`), identical for every partition of the spots, and never
+            materialised on the host: what a problem of BASELINE config 4's size needs (40 GB of logits; a sharded run with
+            init="reference" draws the FULL plane on every rank like the reference would).
+        gather_result=False (with distributed=True): `train` returns this rank's block `softmax(M)[:, lo:hi]` only
+            (`self.spot_range = (lo, hi)`) instead of assembling the full mapping on every rank."""
         if adata_map is not None:
             raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :151-153)")
+        if init not in ("reference", "device"):
+            raise ValueError("init must be 'reference' (NumPy's stream, like the reference) or 'device'")
+        self._gather_result = bool(gather_result)
+        self.spot_range = None
         lambda_getis_ord = lambda_getis_ord if (lambda_getis_ord and lambda_getis_ord > 0) else 0.0     # reference :170,:174,:179
         lambda_moran = lambda_moran if (lambda_moran and lambda_moran > 0) else 0.0
         lambda_geary = lambda_geary if (lambda_geary and lambda_geary > 0) else 0.0
@@ -181,20 +194,28 @@ class Mapper:
         if sharded:
             _check_same_problem(group, self.device, [S_train.shape[0], S_train.shape[1], G_train.shape[0], 0,
                                                      d is not None, d_source is not None] + [bool(v) for v in lambdas.values()])
+        dev_seed = None
         if M_init is None:
             seed = self.random_state
             if sharded and not seed:
                 seed = _shared_seed(group, self.device)
-            if seed:                                         # reference :148-150 (seed 0 / None => unseeded)
-                np.random.seed(seed=seed)
-            M_init = legacy_normal_f32((S.shape[0], G.shape[0]))     # np.random.normal(0, 1, ...) bit for bit (host_rng.py)
+            if init == "device":                             # generated where it is used, block by block (device_init.py)
+                dev_seed = int(seed) if seed else int(np.random.randint(1, 2**31 - 1))
+                if not sharded:
+                    from .device_init import device_normal
+                    M_init = device_normal(S.shape[0], G.shape[0], self.device, dev_seed)
+            else:
+                if seed:                                     # reference :148-150 (seed 0 / None => unseeded)
+                    np.random.seed(seed=seed)
+                M_init = legacy_normal_f32((S.shape[0], G.shape[0]))     # np.random.normal(0, 1, ...) bit for bit (host_rng.py)
         self._sharded = None
         if sharded:
             from .sharded import make_sharded
             self._sharded = make_sharded(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
                                          device=self.device, precision=gemm_precision, lambdas=lambdas, group=group,
                                          voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
-                                         ct_encode=_to_numpy_f32(ct_encode), spatial_weights=spatial_weights)
+                                         ct_encode=_to_numpy_f32(ct_encode), spatial_weights=spatial_weights,
+                                         device_init_seed=dev_seed if M_init is None else None)
             self._engine = self._sharded.eng
         else:
             self._engine = HipMapperEngine(S_train, G_train, M_init, d=d, d_source=d_source if d is not None else None,
@@ -242,7 +263,10 @@ class Mapper:
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
             if val_each is not None and (t - 1) % val_each == 0:
                 val_rows.append((self._sharded or eng).validate())   # reference :398-403: after optimizer.step() of epoch t-1
-        if self._sharded is not None:
+        if self._sharded is not None and not self._gather_result:
+            P_local, self.spot_range = self._sharded.result_local()      # this rank's spots only (gather_result=False)
+            output = P_local.detach().cpu().numpy()
+        elif self._sharded is not None:
             output = self._sharded.result_full(host=True)    # block by block: no rank holds two full C x V copies on its GPU
         else:
             output = eng.result().detach().cpu().numpy()     # reference :406-408
@@ -296,9 +320,16 @@ class MapperConstrained:
         F_init=None,
         distributed=False,
         group=None,
+        init="reference",
+        gather_result=True,
     ):
+        """`init` / `gather_result`: as for `Mapper` (init="device" also draws the filter logits F from the device generator)."""
         if adata_map is not None:
             raise NotImplementedError("resuming from adata_map is not implemented (neither is it in the reference, :476-478)")
+        if init not in ("reference", "device"):
+            raise ValueError("init must be 'reference' (NumPy's stream, like the reference) or 'device'")
+        self._gather_result = bool(gather_result)
+        self.spot_range = None
         self.device = torch.device(device)
         self.random_state = random_state
         S = _to_numpy_f32(S)
@@ -314,20 +345,28 @@ class MapperConstrained:
         if sharded:
             _check_same_problem(group, self.device, [S.shape[0], S.shape[1], G.shape[0], 1, d is not None, 0] +
                                 [bool(v) for v in lambdas.values()])
+        dev_seed = None
         if M_init is None or F_init is None:
             seed = self.random_state
             if sharded and not seed:                                                       # (every rank must draw the same M and F)
                 seed = _shared_seed(group, self.device)
-            if seed:                                                                       # :473-474
-                np.random.seed(seed=seed)
-            legacy_normal_f32((S.shape[0], G.shape[0]), discard=True)                      # :475 (first draw is discarded by :485)
-            M_init = legacy_normal_f32((S.shape[0], G.shape[0]))                           # :485
-            F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)                 # :490
+            if init == "device":
+                from .device_init import device_normal
+                dev_seed = int(seed) if seed else int(np.random.randint(1, 2**31 - 1))
+                M_init = None if sharded else device_normal(S.shape[0], G.shape[0], self.device, dev_seed)
+                F_init = device_normal(1, S.shape[0], self.device, dev_seed, stream_id=1).reshape(-1)
+            else:
+                if seed:                                                                   # :473-474
+                    np.random.seed(seed=seed)
+                legacy_normal_f32((S.shape[0], G.shape[0]), discard=True)                  # :475 (first draw is discarded by :485)
+                M_init = legacy_normal_f32((S.shape[0], G.shape[0]))                       # :485
+                F_init = np.random.normal(0, 1, S.shape[0]).astype(np.float32)             # :490
         self._sharded = None
         if sharded:
             from .sharded import make_sharded
             self._sharded = make_sharded(S, G, M_init, d=d, F0=F_init, mode="constrained", device=self.device,
-                                         precision=gemm_precision, lambdas=lambdas, target_count=float(self.target_count), group=group)
+                                         precision=gemm_precision, lambdas=lambdas, target_count=float(self.target_count), group=group,
+                                         device_init_seed=dev_seed if M_init is None else None)
             self._engine = self._sharded.eng
         else:
             self._engine = HipMapperEngine(S, G, M_init, d=d, F0=F_init, mode="constrained", device=self.device,
@@ -354,7 +393,9 @@ class MapperConstrained:
             if print_each and (t - 1) % print_each == 0 and not (self._sharded is not None and self._rank != 0):
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES_CONSTRAINED])
-        if self._sharded is not None:
+        if self._sharded is not None and not self._gather_result:
+            P, self.spot_range, F = self._sharded.result_local(with_filter=True)
+        elif self._sharded is not None:
             P, F = (torch.as_tensor(x) for x in self._sharded.result_full(with_filter=True, host=True))
         else:
             P, F = eng.result(with_filter=True)

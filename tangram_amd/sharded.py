@@ -189,6 +189,15 @@ class ShardedMapperEngine:
         """Kept for callers of the earlier API: the rows written by `run` are already the global history."""
         return history
 
+    def result_local(self, with_filter=False):
+        """This rank's block of the mapping only: (softmax(M)[:, lo:hi] as a device tensor, (lo, hi)[, filter]) -- nothing is
+        gathered (config 4: the full mapping is 40 GB; 8 ranks each returning it would be 320 GB of host memory)."""
+        lo, hi = shard_bounds(self.n_spots_total, self.world, self.rank, self.spatial)
+        if with_filter:
+            P_local, F = self.eng.result(with_filter=True)
+            return P_local, (lo, hi), F
+        return self.eng.result(), (lo, hi)
+
     def result_full(self, with_filter=False, host=False):
         """The column blocks of softmax(M) of every rank -> [C, V_total] on every rank (+ the replicated filter).
         `host=True`: a NumPy array assembled block by block (one rank's block is broadcast at a time), so that no GPU ever holds
@@ -250,9 +259,11 @@ class ShardedMapperEngine:
 
 def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapper", precision="bf16x3", lambdas=None,
                  target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None, transport="auto",
-                 voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
+                 voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None, device_init_seed=None):
     """Slice full problem arrays (identical on every rank) into this rank's spot block.  The spot graphs of the spatial terms
-    (`voxel_weights`, `neighborhood_filter`, `spatial_weights`: V x V over ALL spots) and `ct_encode` are passed whole."""
+    (`voxel_weights`, `neighborhood_filter`, `spatial_weights`: V x V over ALL spots) and `ct_encode` are passed whole.
+    `device_init_seed` (with M0 = None): this rank's block of the initial logits is generated on ITS device
+    (device_init.device_normal: the same logits whatever the number of ranks) -- the cells x spots plane never exists on a host."""
     pc = comm if comm is not None else DistComm(group)
     world, rank = pc.world, pc.rank
     V = G.shape[0]
@@ -267,11 +278,14 @@ def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapp
                          + (", blocks of ceil(V / world) spots for the spatial terms" if spatial else "") + ")")
     lo, hi = shard_bounds(V, world, rank, spatial)
     G_l = G[lo:hi]
-    M_l = M0[:, lo:hi]
-    if isinstance(M_l, np.ndarray):
-        M_l = np.ascontiguousarray(M_l)
+    if M0 is None:
+        if device_init_seed is None:
+            raise ValueError("make_sharded needs M0 or device_init_seed")
+        from .device_init import device_normal
+        M_l = device_normal(S.shape[0], hi - lo, device, device_init_seed, col0=lo, n_cols_total=V)
     else:
-        M_l = M_l.contiguous()
+        M_l = M0[:, lo:hi]
+        M_l = np.ascontiguousarray(M_l) if isinstance(M_l, np.ndarray) else M_l.contiguous()
     d_l = None if d is None else d[lo:hi]
     return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, F0, n_spots_total=V, device=device, mode=mode, precision=precision,
                                lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, tile_size=tile_size,

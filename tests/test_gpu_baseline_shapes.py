@@ -321,3 +321,67 @@ def test_arrays_beyond_2_pow_32_elements_against_reference_op_sequence():
     P_tail = torch.softmax(e.logits()[0][C - 8:, :V], dim=1)
     assert torch.allclose(P_tail.sum(dim=1), torch.ones(8, device=DEV), atol=1e-5)
     e.release()
+
+
+def test_full_size_properties_cfg4():
+    """BASELINE config 4 at FULL size on one GPU (200 000 x 2 000 x 50 000, bf16 GEMM operands, fp32 state: 120 GB of logits and Adam
+    moments, every C x V array beyond 2^32 elements), started from the seam's device-side initialiser (`Mapper(init="device")`'s
+    generator -- the reference's host draw of this plane is 80 GB of float64).  Neither the reference nor the oracle can run this
+    size: size-independent invariants (mapping_optimizer.py:201-221, tests/tangram_test.py:159-210)."""
+    import gc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.device_init import device_normal
+    from tangram_amd.synthetic import make_workload
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 250 * (1 << 30):
+        pytest.skip(f"needs ~230 GB of free HBM, {free >> 30} GB free")
+    C, K, V = 200000, 2000, 50000
+    w = make_workload(C, K, V, DEV, seed=0)
+    M0 = device_normal(C, V, DEV, seed=42)
+    first = M0[:2].clone(), M0[-2:].clone()
+    e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=DEV, precision="bf16", lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+    del M0
+    torch.cuda.empty_cache()
+    M, m1, m2, _ = e.logits()
+    assert M.shape[0] * M.shape[1] > 2 ** 32
+    assert torch.equal(M[:2, :V], first[0]) and torch.equal(M[-2:, :V], first[1])          # the logits landed where they belong, also past 2^32
+    n = 6
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    h = hist.cpu().numpy()
+    assert np.isfinite(h[:, [0, 1, 3]]).all()
+    assert (np.diff(h[:, 1]) > 0).all(), "gene-voxel score must increase in the first epochs"
+    assert (np.diff(h[:, 3]) < 0).all(), "KL density term must decrease"
+    P = e.result()                                                                         # 40 GB
+    rs = P.sum(dim=1)
+    assert float((rs - 1).abs().max()) < 1e-4 and float(P.min()) >= 0.0
+    # every cell row moved, in particular those whose elements sit beyond a 32-bit index (cells >= 2^32 / pitch = 85 8xx)
+    moved = (m1[:, :V].abs().amax(dim=1) > 0)
+    assert bool(moved.all()), f"{int((~moved).sum())} cell rows were never updated"
+    del rs, moved
+    # train-score invariant: the gene score of the NEXT step is the cosine recomputed from P (bf16 operands in the library's GEMM)
+    Gp = torch.empty((V, K), dtype=torch.float32, device=DEV)
+    for k0 in range(0, K, 500):                                                            # (fp32 P^T S in gene blocks)
+        Gp[:, k0:k0 + 500] = P.t() @ w["S"][:, k0:k0 + 500]
+    cos = torch.nn.functional.cosine_similarity(Gp, w["G"], dim=0).mean().item()
+    colsum = P.sum(dim=0)
+    kl = float((torch.xlogy(w["d"], w["d"]) - w["d"] * torch.log(colsum / C)).sum().item())        # KLDivLoss(reduction="sum"), :218
+    del Gp, colsum
+    hist2 = e.new_history(1)
+    e.step(1, 0.1, hist2)
+    assert abs(cos - float(hist2[0, 1].item())) < 1e-3, (cos, float(hist2[0, 1].item()))
+    assert abs(kl - float(hist2[0, 3].item())) < 1e-4 * max(1.0, abs(kl)), (kl, float(hist2[0, 3].item()))
+    # softmax statistics carried from step to step equal a from-scratch softmax: first rows and rows past the 32-bit mark
+    del P
+    torch.cuda.empty_cache()
+    P_now = e.result()
+    for rows in (slice(0, 1024), slice(C - 1024, C), slice(86000, 87024)):
+        ref = torch.softmax(M[rows, :V], dim=1)
+        assert float((P_now[rows] - ref).abs().max()) < 1e-6
+    assert e.logits()[3] == n + 1
+    e.release()
+    del P_now, M, m1, m2, w
+    gc.collect()
+    torch.cuda.empty_cache()
