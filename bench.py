@@ -253,6 +253,8 @@ def parse_args():
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0, help="force the GEMM tile edge (128 or 256); 0 = automatic")
     ap.add_argument("--bands", type=int, default=0, help="cell bands of the opt-in 3-stream pipeline (0/1 = sequential schedule, the default)")
+    ap.add_argument("--s-exact", action="store_true", help="bf16x3 only: let the library use the two-product path when it finds S bf16-exact "
+                                                            "(the synthetic counts are); the default line times the GENERAL three-product path")
     return ap.parse_args()
 
 
@@ -322,13 +324,14 @@ def main():
     else:
         lam = dict(lambda_g1=1.0, lambda_d=1.0)        # mode='cells' defaults as resolved by mapping_utils.py:214-215
 
-    def make_engine(prec):
+    def make_engine(prec, s_exact=None):
+        s_exact = ("auto" if args.s_exact else False) if s_exact is None else s_exact
         if world == 1:
             M0 = init_logits(C, V, device, seed=42)
             if mode == "constrained":
                 extra["F0"] = torch.randn(C, device=device, generator=torch.Generator(device=device).manual_seed(7))
             e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=device, precision=prec, lambdas=lam,
-                                fwd_splits=args.splits, tile_size=args.tile, pipeline_bands=args.bands, **extra)
+                                fwd_splits=args.splits, tile_size=args.tile, pipeline_bands=args.bands, s_exact=s_exact, **extra)
             return e, e, (lambda n, h=None: e.step(n, lr, h))
         lo, hi = shard_bounds(V, world, rank, mode == "spatial")      # (spatial terms: blocks of ceil(V / world) spots)
         M0 = init_logits(C, hi - lo, device, seed=42 + rank)
@@ -337,10 +340,11 @@ def main():
             kw["F0"] = torch.randn(C, device=device, generator=torch.Generator(device=device).manual_seed(7))
         sh = ShardedMapperEngine(w["S"], w["G"][lo:hi].contiguous(), M0, w["d"][lo:hi].contiguous(), n_spots_total=V,
                                  device=device, precision=prec, lambdas=lam, fwd_splits=args.splits, tile_size=args.tile,
-                                 spot_offset=lo, **kw)
+                                 spot_offset=lo, s_exact=s_exact, **kw)
         return sh, sh.eng, (lambda n, h=None: sh.run(n, lr, h))
 
     owner, core, run = make_engine(precision)
+    eff_prec = getattr(core, "effective_precision", precision)
     torch.cuda.empty_cache()
 
     def fence():
@@ -384,8 +388,12 @@ def main():
         owner.release() if hasattr(owner, "release") else None
         del owner, core, run
         torch.cuda.empty_cache()
-        for prec in [p for p in ("bf16x3", "bf16", "fp32") if p != precision]:
-            e2, _, run2 = make_engine(prec)
+        alts = [(p, None) for p in ("bf16x3", "bf16", "fp32") if p != precision]
+        if precision == "bf16x3" and not args.s_exact:
+            alts.insert(0, ("bf16x3_s_exact", "auto"))       # the opt-in two-product path (S of the synthetic workload is bf16-exact counts)
+        for prec_name, se in alts:
+            prec = "bf16x3" if prec_name == "bf16x3_s_exact" else prec_name
+            e2, _, run2 = make_engine(prec, se)
             n2 = max(4, min(args.steps // 4, 50))
             run2(3)
             torch.cuda.synchronize(device)
@@ -393,7 +401,8 @@ def main():
             run2(n2)
             torch.cuda.synchronize(device)
             dt = (time.perf_counter() - t1) / n2
-            alt[prec] = {"value": 1.0 / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt, "steps": n2, "dtype": DTYPE_NAME[prec],
+            alt[prec_name] = {"value": 1.0 / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt, "steps": n2, "dtype": DTYPE_NAME[prec],
+                         "effective_precision": getattr(e2, "effective_precision", None),
                          "roofline": dict(roof_of(24.0 * C * V + 8.0 * (C * K + V * K), 4.0 * C * V * K, dt, prec),
                                           scope="one iteration", hbm_frac=(24.0 * C * V + 8.0 * (C * K + V * K)) / dt / HBM_PEAK,
                                           mfma_frac=4.0 * C * V * K / dt / MFMA_PEAK[prec])}
@@ -471,6 +480,7 @@ def main():
             "dtype": DTYPE_NAME[precision], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {C} cells x {K} genes x {V} spots, {wl_desc}; planted-mapping synthetic "
                                    f"counts, Adam lr=0.1", "gemm_precision": precision,
+                       "effective_precision": eff_prec,
                        "parallelism": "single GPU" if world == 1 else
                        f"spots sharded over {world} ranks, 3 small exchanges/step issued by the library ({getattr(owner, 'transport', '?')}: "
                        f"{'RCCL on the compute stream' if getattr(owner, 'transport', '') == 'rccl' else backend + ' through callbacks'})"},

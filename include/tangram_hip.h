@@ -82,6 +82,13 @@ typedef struct tg_config {
                                 tests).  The stored product X is bit-identical for both; the row-dot partials of a spot shard depend on
                                 the tile width, which is why the rule is a function of the shape alone (never of a timing).            */
     int32_t spot_offset;     /* spot shard: index of this shard's first spot among the n_spots_total spots (0 on one GPU)            */
+    int32_t s_exact_mode;    /* TG_PREC_BF16X3 only.  0 (default): the general three-product split-bf16 path.  1 (opt-in): tg_mapper_create
+                                checks once whether every element of S (and of the augmentation columns that ride with it: d_source, the
+                                cell-type encoding) is exactly representable in bf16 -- raw counts below 256 are -- and, if so, runs both
+                                GEMMs with TWO matrix-core products per element instead of three: the lo part of S is identically zero,
+                                the product a_hi * S_lo adds exact zeros and is skipped; the results are those of the three-product path
+                                (bit for bit, up to the sign of an exact zero).  If S is not exact the general path runs.  The check
+                                reads one flag back: create then synchronises the stream once.  (ABI version 4.)                   */
 } tg_config;
 
 typedef struct tg_sizes {
@@ -247,7 +254,10 @@ int tg_mapper_validate(tg_mapper* m, float* out4_dev);
 /* Checkpoint access (the reference's adata_map resume is a stub, mapping_optimizer.py:151-153):
  * raw pointers to M / Adam m / Adam v inside `state` and the step counter.                          */
 int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, float** m2_dev, int32_t* pitch, int64_t* step);
-int tg_mapper_set_step(tg_mapper* m, int64_t step);   /* after restoring state: recompute softmax statistics */
+int tg_mapper_set_step(tg_mapper* m, int64_t step);
+/* The precision the handle computes in: a tg_precision value, or 3 = split bf16 with two matrix-core products per element (S was
+ * found bf16-exact at create, tg_config.s_exact_mode); TG_PREC_F32 for clusters-mode handles (see tg_config.precision). */
+int tg_mapper_effective_precision(const tg_mapper* m);   /* after restoring state: recompute softmax statistics */
 /* Constrained mode: the filter logits F and their two Adam moments, three rows of `pitch` floats (row 0 = F, mapping_optimizer.py:
  * 486-493; rows 1, 2 = exp_avg, exp_avg_sq of torch.optim.Adam).  A checkpoint = these + tg_mapper_state; restore into a fresh
  * handle, then tg_mapper_set_step.  The resumed run equals the uninterrupted one up to the rounding of the softmax normaliser

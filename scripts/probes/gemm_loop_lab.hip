@@ -22,6 +22,7 @@
 //      no address arithmetic in the loop), issued like 0
 //  14  11 with those buffer copies
 //  15  13 with all copies of a step in MFMA group 0
+//  16  13 without the save / restore of M0 around each copy
 // Every kernel also reports the shader-clock cycles wave 0 of workgroup 0 spent in the loop (s_memtime): effective clock.
 #include "../../tangram_amd/csrc/tg_kernels.h"
 #include <cstdio>
@@ -43,6 +44,23 @@ __device__ __forceinline__ f32x16 mma32x3(const u32x4 (&a)[2], const u32x4 (&b)[
     return c;
 }
 
+// the global_load_lds form of the tile copy (what the library used before round 4; kept here as the probe's baseline)
+template <int ROWS, int NT>
+__device__ __forceinline__ void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, u32x4* tile, int t, int wave,
+                                             int part = 0, int nparts = 1) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        if (i % nparts != part) continue;
+        const int idx = t + i * NT, row = idx >> 3;
+        const int logical = tg_swz(row, idx & 7);
+        tg_glds16_uncounted(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
+    }
+}
+// LDS-DMA through a buffer descriptor, M0 written but NOT restored (VAR 16: is the save / restore pair worth anything?)
+__device__ __forceinline__ void glds16_buf_nosave(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
 // LDS-DMA through a buffer descriptor: source = descriptor base + lane offset (VGPR, fixed per tile) + soffset (SGPR: the step)
 __device__ __forceinline__ void glds16_buf(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     unsigned keep;
@@ -108,9 +126,9 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(const unsigned char* dG, co
     const int v0 = vt * GE::TM, c0 = ct * GE::TN;
     const size_t pitch = (size_t)nsteps * 128;
     constexpr bool F32 = (VAR == 2 || VAR == 4 || VAR == 5);
-    constexpr bool BUF = (VAR == 13 || VAR == 14 || VAR == 15);
+    constexpr bool BUF = (VAR == 13 || VAR == 14 || VAR == 15 || VAR == 16);
     constexpr bool DMA = BUF || (VAR == 0 || VAR == 5 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 11 || VAR == 12);
-    constexpr bool BAR = VAR == 13 || VAR == 15 || (VAR == 0 || VAR == 5 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || VAR == 12);
+    constexpr bool BAR = VAR == 13 || VAR == 15 || VAR == 16 || (VAR == 0 || VAR == 5 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || VAR == 12);
     f32x4 acc[GE::FM][GE::FN];
     f32x16 acc32[4][2];
 #pragma unroll
@@ -135,6 +153,11 @@ __global__ void __launch_bounds__(512, 2) lab_kernel(const unsigned char* dG, co
     auto buf_copy = [&](int k, int step, int stage) {             // copy k (0 .. LA+LB-1) of `step` into `stage`
         const unsigned dst = ldsbase + stage * GE::STAGE_BYTES + ((k < GE::LA ? k : GE::LA + (k - GE::LA)) * GE::NT + wave * 64) * 16
                              + (k < GE::LA ? 0 : (GE::A_CHUNKS - GE::LA * GE::NT) * 16);
+        if (VAR == 16) {
+            if (k < GE::LA) glds16_buf_nosave(rsA, voffA[k], (unsigned)step * 128u, dst);
+            else glds16_buf_nosave(rsB, voffB[k - GE::LA], (unsigned)step * 128u, dst);
+            return;
+        }
         if (k < GE::LA) glds16_buf(rsA, voffA[k], (unsigned)step * 128u, dst);
         else glds16_buf(rsB, voffB[k - GE::LA], (unsigned)step * 128u, dst);
     };
@@ -300,12 +323,13 @@ int main() {
                            "32x32x16 rolling, LDS reads + MFMA", "32x32x16 rolling, DMA + barrier", "lib loop, no barrier (timing only)",
                            "lib loop, copies by waves 0-3", "lib loop, copies phase-shifted by half", "lib loop, copies by even waves",
                            "LDS reads + MFMA + barrier (no DMA)", "MFMA only + copies (no LDS reads)", "lib loop, copies in group 0",
-                           "lib loop, buffer copies", "MFMA only + buffer copies", "lib loop, buffer copies in group 0"};
+                           "lib loop, buffer copies", "MFMA only + buffer copies", "lib loop, buffer copies in group 0",
+                           "lib loop, buffer copies, M0 not restored"};
     std::vector<float> host((size_t)512);
     typedef float (*runner)(const unsigned char*, const unsigned char*, int, TgTileMap, float*, int, unsigned long long*);
-    runner runs[] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>, run<13>, run<14>, run<15>};
+    runner runs[] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>, run<13>, run<14>, run<15>, run<16>};
     for (int round = 0; round < 3; ++round) {
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < 17; ++v) {
             const float ms = runs[v](dG, Sk, nsteps, map, sink, 10, cyc);
             hipMemcpy(host.data(), sink, 512 * 4, hipMemcpyDeviceToHost);
             double c = 0; for (float x : host) c += x;

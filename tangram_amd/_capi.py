@@ -30,7 +30,7 @@ class TgConfig(ct.Structure):
                [(n, ct.c_int32) for n in ("n_cell_types", "nnz_w", "nnz_n")] + \
                [(n, ct.c_float) for n in ("lambda_getis_ord", "lambda_moran", "lambda_geary")] + [("nnz_s", ct.c_int32)] + \
                [(n, ct.c_float) for n in ("beta1", "beta2", "eps")] + \
-               [(n, ct.c_int32) for n in ("n_ranks", "bwd_tile", "spot_offset")]
+               [(n, ct.c_int32) for n in ("n_ranks", "bwd_tile", "spot_offset", "s_exact_mode")]
 
 
 ALL_REDUCE_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_void_p)                 # tg_all_reduce_sum_fn
@@ -90,6 +90,8 @@ def _declare(lib):
     lib.tg_mapper_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(vp), ct.POINTER(ct.c_int32),
                                     ct.POINTER(ct.c_int64)]
     lib.tg_mapper_set_step.argtypes = [vp, ct.c_int64]
+    lib.tg_mapper_effective_precision.argtypes = [vp]
+    lib.tg_mapper_effective_precision.restype = i32
     lib.tg_mapper_filter_state.argtypes = [vp, ct.POINTER(vp), ct.POINTER(ct.c_int32)]
     lib.tg_mapper_filter_state.restype = i32
     lib.tg_mapper_validate.argtypes = [vp, vp]
@@ -109,7 +111,7 @@ EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_creat
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
            "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step",
            "tg_mapper_filter_state", "tg_mapper_profile",
-           "tg_mapper_profile_read", "tg_mapper_validate", "tg_init_logits_normal"]
+           "tg_mapper_profile_read", "tg_mapper_validate", "tg_init_logits_normal", "tg_mapper_effective_precision"]
 
 
 def lib():

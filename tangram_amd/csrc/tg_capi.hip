@@ -116,6 +116,8 @@ static int tg_launch_status() {
 }
 #define TG_LAUNCH_CK() do { int _rc = tg_launch_status(); if (_rc) return _rc; } while (0)
 extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
+// internal precision code of a handle whose S is bf16-exact (PrecBF16x2S, tg_device.h): never accepted from a caller's tg_config
+enum { TG_PREC_BF16X2S = 3 };
 
 static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
@@ -431,8 +433,7 @@ static int tg_lds_attr() {
         }                                                                                                          \
     } while (0)
 // ---- set-up ------------------------------------------------------------------------------------
-template <class PR>
-static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
+static TgPrepSArgs tg_prep_s_args(tg_mapper* m, const tg_inputs* in) {
     const TgLayout& L = m->L;
     TgPrepSArgs a;
     a.S = in->S_dev; a.C = L.C; a.K = L.K; a.ldS = L.K;
@@ -440,6 +441,33 @@ static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
     a.ct = L.has_ct ? in->ct_encode_dev : nullptr; a.T = L.T_ct;
     a.Sk = m->ws + L.o_Sk; a.Cr = L.Cr; a.Kp = L.Kp;
     a.St = m->ws + L.o_St; a.Cp = L.Cp;
+    return a;
+}
+// Is S (with its augmentation columns) exactly representable in bf16?  One elementwise pass and ONE 4-byte read-back: the only
+// point where tg_mapper_create waits for the stream (only with tg_config.s_exact_mode = 1).  *exact = 1 / 0.
+static int tg_s_is_exact(tg_mapper* m, const tg_inputs* in, int* exact) {
+    const TgLayout& L = m->L;
+    int* flag = (int*)(m->fp(L.o_fsum) + 48);              // (64 floats of scratch, zeroed with the workspace; [0] is the filter sum)
+    const size_t n = (size_t)L.C * (L.K + 1 + L.T_ct);
+    const int grid = (int)(n / 1024 + 1 < 4096 ? n / 1024 + 1 : 4096);
+    TG_LAUNCH(tg_s_exact_check, grid, 1, 256, 0, m->stream, tg_prep_s_args(m, in), flag);
+    TG_LAUNCH_CK();
+    int h = 1;
+#ifdef TG_SIM
+    h = *flag; *flag = 0;
+#else
+    TG_CK(hipMemcpyAsync(&h, flag, sizeof h, hipMemcpyDeviceToHost, m->stream));
+    TG_CK(hipStreamSynchronize(m->stream));
+    TG_CK(hipMemsetAsync(flag, 0, sizeof h, m->stream));
+#endif
+    *exact = (h == 0) ? 1 : 0;
+    return TG_OK;
+}
+
+template <class PR>
+static int tg_setup_operands(tg_mapper* m, const tg_inputs* in) {
+    const TgLayout& L = m->L;
+    const TgPrepSArgs a = tg_prep_s_args(m, in);
     const size_t n1 = (size_t)L.Cr * (L.Kp / PR::CH), n2 = (size_t)L.Kp * (L.Cp / PR::CH);
     TG_LAUNCH((tg_prep_sk<PR>), (n1 + 255) / 256, 1, 256, 0, m->stream, a);
     TG_LAUNCH((tg_prep_st<PR>), (n2 + 255) / 256, 1, 256, 0, m->stream, a);
@@ -702,9 +730,17 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     if (cfg->has_d_source && tg_memcpy(m->ws + L.o_densw, in->d_source_dev, (size_t)L.C * 4, m->stream))
         return bail(tg_fail(TG_ERR_HIP, "copy of d_source failed"));
 
+    if (cfg->precision == TG_PREC_BF16X3 && m->cfg.s_exact_mode == 1) {      // bf16-exact S: two products per element instead of three
+        int exact = 0;
+        if ((rc = tg_s_is_exact(m, in, &exact))) return bail(rc);
+        if (exact) { m->cfg.precision = TG_PREC_BF16X2S; m->L.prec = TG_PREC_BF16X2S; }
+    }
     switch (cfg->precision) {
         case TG_PREC_F32: rc = tg_setup_operands<PrecF32>(m, in); break;
         case TG_PREC_BF16: rc = tg_setup_operands<PrecBF16>(m, in); break;
+        case TG_PREC_BF16X2S: rc = tg_setup_operands<PrecBF16x2S>(m, in);
+                              if (!rc) rc = L.T == 256 ? tg_lds_attr<PrecBF16x3, TgGeoLarge>() : tg_lds_attr<PrecBF16x3, TgGeoSmall>();   // (tg_mapper_project_genes)
+                              break;
         default: rc = tg_setup_operands<PrecBF16x3>(m, in); break;
     }
     if (rc) return bail(rc);
@@ -1407,6 +1443,7 @@ extern "C" int tg_batch_step(tg_batch* b, int n_steps, float lr, float* const* h
     switch (b->h[0]->cfg.precision) {
         case TG_PREC_F32: return tg_batch_step_impl<PrecF32>(b, n_steps, lr, history_dev, first_row);
         case TG_PREC_BF16: return tg_batch_step_impl<PrecBF16>(b, n_steps, lr, history_dev, first_row);
+        case TG_PREC_BF16X2S: return tg_batch_step_impl<PrecBF16x2S>(b, n_steps, lr, history_dev, first_row);
         default: return tg_batch_step_impl<PrecBF16x3>(b, n_steps, lr, history_dev, first_row);
     }
 }
@@ -1582,6 +1619,7 @@ static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row, bool prelau
         switch (m->cfg.precision) {
             case TG_PREC_F32: return tg_one_step_sharded<PrecF32>(m, lr, hist_row);
             case TG_PREC_BF16: return tg_one_step_sharded<PrecBF16>(m, lr, hist_row);
+            case TG_PREC_BF16X2S: return tg_one_step_sharded<PrecBF16x2S>(m, lr, hist_row);
             default: return tg_one_step_sharded<PrecBF16x3>(m, lr, hist_row);
         }
     }
@@ -1589,12 +1627,14 @@ static int tg_dispatch_step(tg_mapper* m, float lr, float* hist_row, bool prelau
         switch (m->cfg.precision) {
             case TG_PREC_F32: return tg_one_step_pipelined<PrecF32>(m, lr, hist_row, prelaunched, prelaunch_next);
             case TG_PREC_BF16: return tg_one_step_pipelined<PrecBF16>(m, lr, hist_row, prelaunched, prelaunch_next);
+            case TG_PREC_BF16X2S: return tg_one_step_pipelined<PrecBF16x2S>(m, lr, hist_row, prelaunched, prelaunch_next);
             default: return tg_one_step_pipelined<PrecBF16x3>(m, lr, hist_row, prelaunched, prelaunch_next);
         }
     }
     switch (m->cfg.precision) {
         case TG_PREC_F32: return tg_one_step<PrecF32>(m, lr, hist_row);
         case TG_PREC_BF16: return tg_one_step<PrecBF16>(m, lr, hist_row);
+        case TG_PREC_BF16X2S: return tg_one_step<PrecBF16x2S>(m, lr, hist_row);
         default: return tg_one_step<PrecBF16x3>(m, lr, hist_row);
     }
 }
@@ -1638,6 +1678,7 @@ extern "C" int tg_mapper_project(tg_mapper* m, float* Ghat_out_dev) {
     switch (m->cfg.precision) {
         case TG_PREC_F32: rc = tg_launch_forward<PrecF32>(m); break;
         case TG_PREC_BF16: rc = tg_launch_forward<PrecBF16>(m); break;
+        case TG_PREC_BF16X2S: rc = tg_launch_forward<PrecBF16x2S>(m); break;
         default: rc = tg_launch_forward<PrecBF16x3>(m); break;
     }
     if (rc) return rc;
@@ -1743,6 +1784,10 @@ extern "C" int tg_cluster_aggregate(const float* X_dev, int64_t ld, int32_t n_co
     return TG_OK;
 }
 
+// The precision a handle really computes in: tg_precision, or 3 = split bf16 with two products per element (S found bf16-exact at
+// tg_mapper_create, tg_config.s_exact_mode).  Clusters-mode handles report TG_PREC_F32 (tg_make_layout).
+extern "C" int tg_mapper_effective_precision(const tg_mapper* m) { return m ? m->cfg.precision : -1; }
+
 extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper not ready");
     if (!out4_dev) return tg_fail(TG_ERR_INVALID, "out is NULL");
@@ -1753,6 +1798,7 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     switch (m->cfg.precision) {
         case TG_PREC_F32: rc = tg_launch_forward<PrecF32>(m); break;
         case TG_PREC_BF16: rc = tg_launch_forward<PrecBF16>(m); break;
+        case TG_PREC_BF16X2S: rc = tg_launch_forward<PrecBF16x2S>(m); break;
         default: rc = tg_launch_forward<PrecBF16x3>(m); break;
     }
     if (rc) return rc;

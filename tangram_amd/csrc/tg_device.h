@@ -77,6 +77,13 @@ TG_DEV void tg_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
 }
 TG_DEV void tg_glds16_uncounted(const unsigned char* src, unsigned char* lds_wave_base) { tg_glds16(src, lds_wave_base); }
 TG_DEV void tg_dma_drain() {}
+TG_DEV void tg_flag_or(int* p, int v) { *p |= v; }
+// buffer-descriptor form of the copy (see the HIP build below): descriptor = {base pointer, byte count}
+struct TgRsrc { const unsigned char* base; unsigned bytes; };
+TG_DEV TgRsrc tg_make_rsrc(const unsigned char* base, size_t bytes) { return TgRsrc{base, (unsigned)bytes}; }
+TG_DEV void tg_glds16_buf(const TgRsrc& r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    tg_glds16(r.base + (size_t)voff + soff, lds_wave_base);
+}
 #else
 // ------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
@@ -135,6 +142,26 @@ TG_DEV void tg_glds16_uncounted(const unsigned char* src, unsigned char* lds_wav
 // its own vector loads count as complete afterwards (an asm wait would leave them pending on some paths of its scoreboard,
 // and the next write to one of their registers then gets a vmcnt(0) of its own in the middle of the MFMA stream).
 TG_DEV void tg_dma_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+TG_DEV void tg_flag_or(int* p, int v) { atomicOr(p, v); }
+// The copy through a BUFFER DESCRIPTOR: buffer_load_dwordx4 ... offen lds.  Source = descriptor base (SGPRs) + this lane's byte
+// offset (one VGPR, fixed for the whole tile) + soffset (an SGPR: the contraction step).  Against the global_load_lds form (64-bit
+// lane addresses rebuilt by two VALU instructions per copy and step) the loop carries no address arithmetic at all, and the copy
+// itself is cheaper to issue: the backward main loop -2.3 % (scripts/probes/gemm_loop_lab.hip, VAR 13 vs 0, profiles/r04/lab).
+// Out-of-range offsets cannot fault: the hardware clamps buffer accesses to the descriptor's byte count.
+typedef u32x4 TgRsrc;
+TG_DEV TgRsrc tg_make_rsrc(const unsigned char* base, size_t bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    TgRsrc r = {(unsigned)b, (unsigned)(b >> 32) & 0xffffu, (unsigned)bytes, 0x00020000u};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+TG_DEV void tg_glds16_buf(const TgRsrc& r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(r), "s"(dst), "s"(soff) : "memory");
+}
 #endif
 
 TG_DEV float tg_bf16_lo_to_f32(unsigned packed) { return __builtin_bit_cast(float, packed << 16); }
@@ -158,6 +185,7 @@ TG_DEV float tg_fmax(float a, float b) { return a > b ? a : b; }
 struct PrecF32 {
     static constexpr bool X16 = false;      // backward product X kept in fp32
     static constexpr int kId = 0, KQ = 2, NP = 1, CH = 4, BKE = 32, ESZ = 4, KCH = 8;
+    static constexpr int NPB = NP, BRC = 8;     // parts of a B fragment; 16-byte chunks per B tile row (see PrecBF16x2S)
     TG_DEVM static void cvt(const float (&x)[4], u32x4& hi, u32x4& lo) {
         hi = u32x4{__builtin_bit_cast(unsigned, x[0]), __builtin_bit_cast(unsigned, x[1]),
                    __builtin_bit_cast(unsigned, x[2]), __builtin_bit_cast(unsigned, x[3])};
@@ -176,6 +204,7 @@ struct PrecF32 {
 struct PrecBF16 {
     static constexpr bool X16 = true;       // X = S dGhat^T is built from bf16 operands: keeping it in bf16 adds no new error class
     static constexpr int kId = 1, KQ = 2, NP = 1, CH = 8, BKE = 64, ESZ = 2, KCH = 8;
+    static constexpr int NPB = NP, BRC = 8;
     TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
         hi = u32x4{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3]), tg_pack_bf16(x[4], x[5]), tg_pack_bf16(x[6], x[7])};
         lo = hi;
@@ -186,6 +215,7 @@ struct PrecBF16 {
 struct PrecBF16x3 {
     static constexpr bool X16 = false;
     static constexpr int kId = 2, KQ = 1, NP = 2, CH = 8, BKE = 32, ESZ = 4, KCH = 4;   // ESZ: bytes per element incl. lo
+    static constexpr int NPB = NP, BRC = 8;
     TG_DEVM static void cvt(const float (&x)[8], u32x4& hi, u32x4& lo) {
         float r[8];
 #pragma unroll
@@ -205,6 +235,27 @@ struct PrecBF16x3 {
     }
 };
 
+// PrecBF16x2S: split bf16 with an EXACT B operand.  In both GEMMs of the iteration the B operand is the constant S (forward:
+// Ghat = P^T S, backward: X = S dGhat^T).  When every element of S (and of the augmentation columns riding with it) is exactly
+// representable in bf16 -- raw counts below 256, one-hot cell types, the uniform density column -- its lo part is identically
+// zero and the product a_hi * b_lo of the split-bf16 scheme adds exact zeros: it is skipped, a*b = a_lo*b_hi + a_hi*b_hi, the
+// SAME value as PrecBF16x3 delivers (bit for bit up to the sign of an exact zero), with 2 matrix-core products instead of 3.
+// The S images then hold hi parts only: B tile rows of 64 bytes (BRC = 4 chunks) instead of 128, half the copy traffic of S.
+// The A operand (softmax(M) / dGhat) keeps the bf16x3 format.  Chosen by the library when it is asked to check S and finds it exact
+// (tg_config.s_exact_mode = 1, tg_mapper_create); never requested by a caller directly.
+struct PrecBF16x2S : PrecBF16x3 {
+    static constexpr int kId = 3, NPB = 1, BRC = 4;
+    TG_DEVM static f32x4 mma(const u32x4* a, const u32x4* b, f32x4 c) {
+        c = tg_mma_bf16(a[1], b[0], c);      // small term first, like PrecBF16x3
+        c = tg_mma_bf16(a[0], b[0], c);
+        return c;
+    }
+};
+// XOR swizzle of a COMPACT (64-byte, 4-chunk) B tile row: the 16-lane groups of a ds_read_b128 (lanes {0-3, 12-15, 20-27}, ...)
+// meet rows r, r+4, r+8, r+12 at chunk g or g^1 -- {0, 3, 2, 1}[(row >> 2) & 3] sends them to four different chunks, i.e. a
+// group covers all 16 slots of the 256-byte bank row.  (Depends on (row >> 2) & 3 only: the same for every 16-row fragment.)
+TG_DEV int tg_swz4(int row, int chunk) { return chunk ^ ((4 - ((row >> 2) & 3)) & 3); }
+
 // Write the operand image of CH consecutive contraction elements (k-chunk `kc` of step `step`) of one operand row.
 template <class PR>
 TG_DEV void tg_store_operand_chunk(unsigned char* row_base, int step, int kc, const float (&x)[PR::CH]) {
@@ -213,6 +264,16 @@ TG_DEV void tg_store_operand_chunk(unsigned char* row_base, int step, int kc, co
     u32x4* dst = (u32x4*)(row_base + (size_t)step * 128);
     dst[kc] = hi;
     if (PR::NP == 2) dst[4 + kc] = lo;
+}
+// ... of the B operand S: the same image, or hi parts only in rows of BRC * 16 bytes per step (PrecBF16x2S)
+template <class PR>
+TG_DEV void tg_store_s_chunk(unsigned char* row_base, int step, int kc, const float (&x)[PR::CH]) {
+    if constexpr (PR::BRC == 8) tg_store_operand_chunk<PR>(row_base, step, kc, x);
+    else {
+        u32x4 hi, lo;
+        PR::cvt(x, hi, lo);
+        ((u32x4*)(row_base + (size_t)step * (PR::BRC * 16)))[kc] = hi;
+    }
 }
 
 // XOR swizzle of the 16-byte chunk index inside a 128-byte LDS tile row: ds_read_b128 of 16

@@ -90,11 +90,13 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
     constexpr int NB = GE::FM / GA;                           // blocks per k-chunk group
     constexpr int NG = PR::KQ * NB;                           // pipeline length (groups per step)
     const int r = lane & 15, g = lane >> 4;
+    constexpr int BRC = PR::BRC;                              // chunks per B tile row: 8, or 4 (hi parts only, PrecBF16x2S)
     const u32x4* sa = st + (wm * (GE::TM / GE::WM) + r) * 8;  // this lane's first A row
-    const u32x4* sb = st + GE::A_CHUNKS + (wn * (GE::TN / GE::WN) + r) * 8;
+    const u32x4* sb = st + GE::A_CHUNKS + (wn * (GE::TN / GE::WN) + r) * BRC;
     // rows of successive fragments differ by 16: (row >> 1) & 7 is the same for all of them, (row >> 4) & 1 alternates
-    const int swr = tg_swz(wm * (GE::TM / GE::WM) + r, 0), swb = tg_swz(wn * (GE::TN / GE::WN) + r, 0);
-    u32x4 a[2][GA][PR::NP], b[2][GE::FN][PR::NP];
+    const int swr = tg_swz(wm * (GE::TM / GE::WM) + r, 0);
+    const int swb = BRC == 8 ? tg_swz(wn * (GE::TN / GE::WN) + r, 0) : tg_swz4(wn * (GE::TN / GE::WN) + r, 0);
+    u32x4 a[2][GA][PR::NP], b[2][GE::FN][PR::NPB];
     auto load_a = [&](int buf, int q, int blk) {
 #pragma unroll
         for (int f = 0; f < GA; ++f)
@@ -105,7 +107,10 @@ TG_DEV void tg_tile_mma(const u32x4* st, int wm, int wn, int lane, f32x4 (&acc)[
 #pragma unroll
         for (int f = 0; f < GE::FN; ++f)
 #pragma unroll
-            for (int p = 0; p < PR::NP; ++p) b[buf][f][p] = sb[f * 128 + ((4 * (q + p) + g) ^ swb ^ (f & 1))];
+            for (int p = 0; p < PR::NPB; ++p) {
+                if constexpr (BRC == 8) b[buf][f][p] = sb[f * 128 + ((4 * (q + p) + g) ^ swb ^ (f & 1))];
+                else b[buf][f][p] = sb[f * 64 + (g ^ swb)];
+            }
     };
     load_b(0, 0);
     load_a(0, 0, 0);
@@ -154,23 +159,43 @@ struct TgMmaShape {
 };
 
 // ROWS x 128-byte slab (one contraction step) of an operand stored as [row][step][128 B], copied by LDS-DMA
-// (global_load_lds_dwordx4): no VGPR round trip, no ds_write.  The LDS image of one
-// wave instruction is lane-linear (64 x 16 B = 8 tile rows), so the XOR swizzle is applied to the per-lane SOURCE
-// address (logical chunk = physical chunk ^ swizzle(row)), the read side applies the same involution.
-// (`part` of `nparts`: the copies i = part, part + nparts, ... only -- for spreading the issue over the MFMA groups)
-// The copies are issued outside hipcc's wait counters (tg_glds16_uncounted): the caller drains them with tg_dma_drain()
-// in front of the barrier that publishes the tile.
-template <int ROWS, int NT>
-TG_DEV void tg_ktile_dma(const unsigned char* base, size_t row0, size_t pitch_bytes, size_t step, u32x4* tile, int t, int wave,
-                         int part = 0, int nparts = 1) {
+// (buffer_load_dwordx4 ... lds): no VGPR round trip, no ds_write.  The LDS image of one wave instruction is lane-linear
+// (64 x 16 B = 8 tile rows), so the XOR swizzle is applied to the per-lane SOURCE offset (logical chunk = physical chunk ^
+// swizzle(row)), the read side applies the same involution.
+// A TgKtileDma is set up once per tile: a buffer descriptor over the tile's ROWS operand rows and this lane's byte offsets of its
+// ROWS * 8 / NT copies; issue(step, ...) then needs no address arithmetic (the step travels in the copy's scalar offset).
+// (`part` of `nparts`: the copies i = part, part + nparts, ... only -- for spreading the issue over the MFMA groups.)
+// The copies are issued outside hipcc's wait counters (tg_device.h): the caller drains them with tg_dma_drain() in front of the
+// barrier that publishes the tile.
+#ifndef TG_DMA_MODE
+#define TG_DMA_MODE 2         // A/B switch of the copy instruction (scripts/build_variant.sh -DTG_DMA_MODE=n): 2 = buffer descriptor (default),
+#endif                        // 1 = global_load_lds from an asm statement, 0 = the builtin, counted by hipcc (round 3's form)
+template <int ROWS, int NT, int RC = 8>      // RC: 16-byte chunks per operand row and step (8; 4 = hi parts only, PrecBF16x2S)
+struct TgKtileDma {
+    static constexpr int N = ROWS * RC / NT;
+    TgRsrc rsrc;
+    const unsigned char* base0;
+    unsigned voff[N];
+    TG_DEVM void setup(const unsigned char* base, size_t row0, size_t pitch_bytes, int t) {
+        base0 = base + row0 * pitch_bytes;
+        rsrc = tg_make_rsrc(base0, (size_t)ROWS * pitch_bytes);
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / NT; ++i) {
-        if (i % nparts != part) continue;
-        const int idx = t + i * NT, row = idx >> 3;
-        const int logical = tg_swz(row, idx & 7);                 // involution: logical = physical ^ s(row)
-        tg_glds16_uncounted(base + (row0 + row) * pitch_bytes + step * 128 + logical * 16, (unsigned char*)(tile + i * NT + wave * 64));
+        for (int i = 0; i < N; ++i) {
+            const int idx = t + i * NT, row = idx / RC;
+            const int logical = RC == 8 ? tg_swz(row, idx & 7) : tg_swz4(row, idx & 3);               // involution: logical = physical ^ s(row)
+            voff[i] = (unsigned)((size_t)row * pitch_bytes) + (unsigned)logical * 16u;
+        }
     }
-}
+    TG_DEVM void issue(int step, u32x4* tile, int wave, int part = 0, int nparts = 1) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i % nparts != part) continue;
+            if (TG_DMA_MODE == 2) tg_glds16_buf(rsrc, voff[i], (unsigned)step * (RC * 16u), (unsigned char*)(tile + i * NT + wave * 64));
+            else if (TG_DMA_MODE == 1) tg_glds16_uncounted(base0 + voff[i] + (size_t)step * (RC * 16), (unsigned char*)(tile + i * NT + wave * 64));
+            else tg_glds16(base0 + voff[i] + (size_t)step * (RC * 16), (unsigned char*)(tile + i * NT + wave * 64));
+        }
+    }
+};
 
 // XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup b to XCD b % 8 (observed, used for speed
 // only: any mapping is correct).  Each XCD owns a contiguous band of the `major` tile axis (n_major / 8 rows, the first
@@ -279,7 +304,10 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
 
     f32x4 mreg[RS];
     float sh[RS], mu[RS];
-    const size_t bpitch = (size_t)a.nsteps * 128;
+    const size_t bpitch = (size_t)a.nsteps * (PR::BRC * 16);
+    constexpr int LBX = GE::TN * PR::BRC / GE::NT;            // copies of the S^T tile per thread and step
+    TgKtileDma<GE::TN, GE::NT, PR::BRC> dmaB;                  // S^T tile: TN gene rows of this workgroup, every step of the cell axis
+    dmaB.setup(a.St, (size_t)k0, bpitch, t);
 
     auto load_m = [&](int step, int j) {                       // one float4 row of the M micro-block of `step`
         if (!stager) return;
@@ -305,7 +333,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     constexpr int GA_F = (PR::NP == 2 ? 1 : 2);                // the M staging registers leave room for small blocks only
     constexpr int NG_F = TgMmaShape<PR, GE, GA_F>::NG;
     constexpr int NSPREAD = (NG_F * 3) / 4 > 0 ? (NG_F * 3) / 4 : 1;
-    constexpr int NITEM = GE::LB + RS + 1;
+    constexpr int NITEM = LBX + RS + 1;
     // (step_m: the step whose M micro-block is fetched -- one step further ahead for the early half of the waves, see below;
     //  step_b: the step whose S^T tile is copied into `st`; a negative step = nothing to fetch)
     auto issue_next = [&](int step_m, int step_b, u32x4* st, int i) {
@@ -314,7 +342,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
             if ((k * NSPREAD) / NITEM != i) continue;
             if (k < RS) { if (step_m >= 0) load_m(step_m, k); }
             else if (k == RS) { if (step_m >= 0) load_sh(step_m); }
-            else if (step_b >= 0) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)step_b, st + GE::A_CHUNKS, t, wave, k - RS - 1, GE::LB);
+            else if (step_b >= 0) dmaB.issue(step_b, st + GE::A_CHUNKS, wave, k - RS - 1, LBX);
         }
     };
     // (MASKED: edge tiles zero the spots >= V; interior tiles skip the 16 selects.  bf16x3: the arithmetic runs on pairs of
@@ -377,7 +405,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
     const bool early = (STAG == 1) ? (wave < GE::NT / 128) : ((STAG == 2) ? (wave >= GE::NT / 128) : false);
     // (every wave early -- all M loads a full step ahead, VALU block first: bf16x3 1.63 ms, bf16 0.77: the M loads do not cost latency)
     if (s_begin < s_end) {
-        tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)s_begin, lds + GE::A_CHUNKS, t, wave);
+        dmaB.issue(s_begin, lds + GE::A_CHUNKS, wave);
         load_stage(s_begin);
         store_stage(lds);
         if (early && s_begin + 1 < s_end) load_stage(s_begin + 1);
@@ -393,7 +421,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
                                                     // (bf16x3: -2 %; slower for the 8-row micro-blocks of bf16, profiles/r01/run26)
                 tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [&](int i) { issue_next(step_m, more ? s + 1 : -1, nxt, i); });
             } else {
-                if (more) tg_ktile_dma<GE::TN, GE::NT>(a.St, (size_t)k0, bpitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave);
+                if (more) dmaB.issue(s + 1, nxt + GE::A_CHUNKS, wave);
                 if (step_m >= 0) load_stage(step_m);
                 tg_tile_mma<PR, GE, GA_F>(cur, wm, wn, lane, acc, [](int) {});
             }
@@ -828,8 +856,13 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
 
     {
         const size_t pitch = (size_t)nsteps * 128;
-        tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, 0, lds, t, wave);
-        tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, 0, lds + GE::A_CHUNKS, t, wave);
+        constexpr int LBX = GE::TN * PR::BRC / GE::NT;        // copies of the S tile per thread and step
+        TgKtileDma<GE::TM, GE::NT> dmaA;
+        TgKtileDma<GE::TN, GE::NT, PR::BRC> dmaB;
+        dmaA.setup(a.dG, (size_t)v0, pitch, t);
+        dmaB.setup(a.Sk, (size_t)c0, (size_t)nsteps * (PR::BRC * 16), t);
+        dmaA.issue(0, lds, wave);
+        dmaB.issue(0, lds + GE::A_CHUNKS, wave);
         tg_dma_drain();
         __syncthreads();
         // The last step is peeled off the loop: inside the loop the DMA issue is unconditional, so a step is ONE basic block
@@ -838,12 +871,12 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
             u32x4* cur = lds + (s & 1) * GE::STAGE_CHUNKS;
             u32x4* nxt = lds + ((s + 1) & 1) * GE::STAGE_CHUNKS;
             tg_tile_mma<PR, GE>(cur, wm, wn, lane, acc, [&](int i) {     // DMA of the next step lands while the matrix cores run,
-                constexpr int NG_B = TgMmaShape<PR, GE>::NG, NSP = (NG_B * 3) / 4 > 0 ? (NG_B * 3) / 4 : 1, NIT = GE::LA + GE::LB;
+                constexpr int NG_B = TgMmaShape<PR, GE>::NG, NSP = (NG_B * 3) / 4 > 0 ? (NG_B * 3) / 4 : 1, NIT = GE::LA + LBX;
 #pragma unroll
                 for (int k = 0; k < NIT; ++k) {                          // issued a few copies per MFMA group (see tg_tile_mma)
                     if ((k * NSP) / NIT != i) continue;
-                    if (k < GE::LA) tg_ktile_dma<GE::TM, GE::NT>(a.dG, (size_t)v0, pitch, (size_t)(s + 1), nxt, t, wave, k, GE::LA);
-                    else tg_ktile_dma<GE::TN, GE::NT>(a.Sk, (size_t)c0, pitch, (size_t)(s + 1), nxt + GE::A_CHUNKS, t, wave, k - GE::LA, GE::LB);
+                    if (k < GE::LA) dmaA.issue(s + 1, nxt, wave, k, GE::LA);
+                    else dmaB.issue(s + 1, nxt + GE::A_CHUNKS, wave, k - GE::LA, LBX);
                 }
             });
             tg_dma_drain();
@@ -2261,7 +2294,7 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_sk(TgPrepSArgs a) {
     float x[PR::CH];
 #pragma unroll
     for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, c, k + e);
-    tg_store_operand_chunk<PR>(a.Sk + (size_t)c * (a.Kp / PR::BKE) * 128, k / PR::BKE, (k % PR::BKE) / PR::CH, x);
+    tg_store_s_chunk<PR>(a.Sk + (size_t)c * (a.Kp / PR::BKE) * (PR::BRC * 16), k / PR::BKE, (k % PR::BKE) / PR::CH, x);
 }
 template <class PR>
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_st(TgPrepSArgs a) {
@@ -2273,7 +2306,19 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_prep_st(TgPrepSArgs a) {
     float x[PR::CH];
 #pragma unroll
     for (int e = 0; e < PR::CH; ++e) x[e] = tg_s_aug(a, c + e, k);
-    tg_store_operand_chunk<PR>(a.St + (size_t)k * (a.Cp / PR::BKE) * 128, c / PR::BKE, (c % PR::BKE) / PR::CH, x);
+    tg_store_s_chunk<PR>(a.St + (size_t)k * (a.Cp / PR::BKE) * (PR::BRC * 16), c / PR::BKE, (c % PR::BKE) / PR::CH, x);
+}
+// Is every element the S images are built from exactly representable in bf16 (then their lo parts are identically zero and
+// PrecBF16x2S applies)?  *flag |= 1 otherwise.  (An integer OR: order-independent.)
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_s_exact_check(TgPrepSArgs a, int* flag) {
+    const size_t n = (size_t)a.C * (a.K + 1 + (a.ct ? a.T : 0));
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / (a.K + 1 + (a.ct ? a.T : 0))), k = (int)(i % (a.K + 1 + (a.ct ? a.T : 0)));
+        const float x = tg_s_aug(a, c, k);
+        bad |= tg_bf16_lo_to_f32(tg_pack_bf16(x, 0.f)) != x;
+    }
+    if (bad) tg_flag_or(flag, 1);
 }
 
 // Gp = zero-padded copy of G; vnorm2[v] = sum_k G^2; gnormpart[rb][k] = partial sum_v G^2

@@ -39,7 +39,7 @@ class HipMapperEngine:
 
     def __init__(self, S, G, M0, d=None, d_source=None, F0=None, *, mode="mapper", device="cuda:0",
                  precision="bf16x3", lambdas=None, n_spots_total=None, n_ranks=0, fwd_splits=0, tile_size=0, pipeline_bands=0,
-                 bwd_tile=0, spot_offset=0,
+                 bwd_tile=0, spot_offset=0, s_exact=False,
                  target_count=0.0, betas=(0.9, 0.999), eps=1e-8,
                  voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
         self.device = torch.device(device)
@@ -80,6 +80,9 @@ class HipMapperEngine:
         cfg.pipeline_bands = int(pipeline_bands)
         cfg.bwd_tile = int(bwd_tile)
         cfg.spot_offset = int(spot_offset)
+        if s_exact not in ("auto", True, False):
+            raise ValueError("s_exact must be False (the general three-product path, default) or 'auto' (check S once at construction)")
+        cfg.s_exact_mode = 0 if s_exact is False else 1
         for k, v in lam.items():
             setattr(cfg, k, float(v))
         cfg.target_count = float(target_count)
@@ -136,10 +139,10 @@ class HipMapperEngine:
         # tile_size not pinned) train on the library's exact-fp32 clusters-mode kernels whatever `gemm_precision` says, and the
         # library then also validates / projects such a handle in fp32 (tg_make_layout): `precision` is what was asked for,
         # `effective_precision` what runs.
-        geo = (ct.c_int * 8)()
-        self.effective_precision = precision
-        if hasattr(self._lib, "tg_debug_layout") and self._lib.tg_debug_layout(ct.byref(cfg), geo) == 0 and geo[7]:
-            self.effective_precision = "fp32"
+        # `bf16x3` on a bf16-exact S (raw counts, one-hot columns): two matrix-core products per element instead of three, the
+        # same results (opt-in: `s_exact="auto"`; the default `s_exact=False` keeps the general path) -> "bf16x3 (S exact: 2 products)".
+        self.effective_precision = {0: "fp32", 1: "bf16", 2: "bf16x3", 3: "bf16x3 (S exact: 2 products)"}.get(
+            int(self._lib.tg_mapper_effective_precision(self._h)), precision)
         self._scratch_row = torch.zeros(_capi.H_NTERMS, dtype=torch.float32, device=self.device)
 
     # -- plumbing ---------------------------------------------------------------------------------

@@ -75,7 +75,8 @@ def rccl_library_path():
 class ShardedMapperEngine:
     def __init__(self, S, G_local, M0_local, d_local=None, d_source=None, F0=None, *, n_spots_total, device, mode="mapper",
                  precision="bf16x3", lambdas=None, target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None,
-                 transport="auto", spot_offset=0, voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None):
+                 transport="auto", spot_offset=0, voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None,
+                 s_exact=False):
         # `comm`: anything with world, rank, all_reduce, all_gather_into_tensor, all_gather (tests drive several shards of one
         # GPU through an in-process communicator); default: the torch.distributed group
         self.pycomm = comm if comm is not None else DistComm(group)
@@ -97,7 +98,7 @@ class ShardedMapperEngine:
                                    precision=precision, lambdas=self.lam, n_spots_total=n_spots_total, n_ranks=self.world,
                                    fwd_splits=fwd_splits, tile_size=tile_size, bwd_tile=bwd_tile, target_count=target_count,
                                    spot_offset=spot_offset, voxel_weights=voxel_weights, neighborhood_filter=neighborhood_filter,
-                                   ct_encode=ct_encode, spatial_weights=spatial_weights)
+                                   ct_encode=ct_encode, spatial_weights=spatial_weights, s_exact=s_exact)
         self.has_density = d_local is not None
         self.n_spots_total = int(n_spots_total)
         lib = self.eng._lib
@@ -259,7 +260,8 @@ class ShardedMapperEngine:
 
 def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapper", precision="bf16x3", lambdas=None,
                  target_count=0.0, group=None, fwd_splits=0, tile_size=0, bwd_tile=0, comm=None, transport="auto",
-                 voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None, device_init_seed=None):
+                 voxel_weights=None, neighborhood_filter=None, ct_encode=None, spatial_weights=None, device_init_seed=None,
+                 s_exact=False):
     """Slice full problem arrays (identical on every rank) into this rank's spot block.  The spot graphs of the spatial terms
     (`voxel_weights`, `neighborhood_filter`, `spatial_weights`: V x V over ALL spots) and `ct_encode` are passed whole.
     `device_init_seed` (with M0 = None): this rank's block of the initial logits is generated on ITS device
@@ -289,5 +291,5 @@ def make_sharded(S, G, M0, d=None, d_source=None, F0=None, *, device, mode="mapp
     d_l = None if d is None else d[lo:hi]
     return ShardedMapperEngine(S, G_l, M_l, d_l, d_source, F0, n_spots_total=V, device=device, mode=mode, precision=precision,
                                lambdas=lambdas, target_count=target_count, group=group, fwd_splits=fwd_splits, tile_size=tile_size,
-                               bwd_tile=bwd_tile, comm=comm, transport=transport, spot_offset=lo, voxel_weights=voxel_weights,
+                               bwd_tile=bwd_tile, comm=comm, transport=transport, spot_offset=lo, s_exact=s_exact, voxel_weights=voxel_weights,
                                neighborhood_filter=neighborhood_filter, ct_encode=ct_encode, spatial_weights=spatial_weights)

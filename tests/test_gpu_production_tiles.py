@@ -290,3 +290,51 @@ def test_rccl_one_rank_group_runs_the_sharded_step():
         assert float(np.abs(Ps - e.result().cpu().numpy()).max()) <= 1e-5     # (summation orders differ: 2e-6 observed)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tile", [256, 128])
+def test_two_product_path_equals_the_general_path_at_production_tiles(oracle_k1000, tile):
+    """`s_exact="auto"` (PrecBF16x2S: S is bf16-exact count data, the product a_hi * S_lo adds exact zeros and is skipped) at K = 1 000:
+    4 gene tiles, 32 backward contraction steps, wide forward tiles, several splits, compact 64-byte S tile rows in LDS.  EQUAL to
+    the three-product path (history, mapping, first Adam moment), and within the fp32 tolerances of the fp64 oracle."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd import _capi
+    o = oracle_k1000
+    data = o["data"]
+    outs = []
+    for se in (False, "auto"):
+        e = HipMapperEngine(data["S"], data["G"], o["M0"], d=data["d"], device=DEV, precision="bf16x3", lambdas=o["lam"], tile_size=tile, s_exact=se)
+        hist = e.new_history(N1)
+        e.step(N1, 0.1, hist)
+        outs.append(dict(h=hist.cpu().numpy(), P=e.result().cpu().numpy(), m1=e.logits()[1].cpu().numpy(), eff=e.effective_precision))
+        e.release()
+    assert outs[0]["eff"] == "bf16x3" and outs[1]["eff"].startswith("bf16x3 (S exact")
+    for k in ("h", "P", "m1"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    h = outs[1]["h"].astype(np.float64)
+    for k, col in (("total_loss", _capi.H_TOTAL), ("main_loss", _capi.H_MAIN), ("vg_reg", _capi.H_VG), ("kl_reg", _capi.H_KL)):
+        assert float(np.abs(h[:, col] - np.asarray(o["hist"][k], dtype=np.float64)).max()) <= pc.TOL["bf16x3"]["loss"], k
+    assert float(np.abs(outs[1]["P"] - o["P"]).max()) <= pc.TOL["bf16x3"]["P"]
+
+
+def test_two_product_path_full_size_cfg2_first_steps_equal():
+    """The BASELINE shape 30 000 x 1 000 x 10 000 (synthetic counts: bf16-exact S): three steps of the two-product path equal the
+    general path's (history bits; mapping bits on a sample of rows)."""
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.synthetic import make_workload, init_logits
+    C, K, V = 30000, 1000, 10000
+    w = make_workload(C, K, V, DEV, seed=0)
+    M0 = init_logits(C, V, DEV, seed=42)
+    res = []
+    for se in (False, "auto"):
+        e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=DEV, precision="bf16x3", lambdas=dict(lambda_g1=1.0, lambda_d=1.0), s_exact=se)
+        hist = e.new_history(3)
+        e.step(3, 0.1, hist)
+        P = e.result()
+        res.append((hist.cpu().numpy(), P[::997].cpu().numpy(), e.effective_precision))
+        e.release()
+        del e, P
+        torch.cuda.empty_cache()
+    assert res[1][2].startswith("bf16x3 (S exact")
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
+    assert np.array_equal(res[0][1], res[1][1])
