@@ -63,7 +63,9 @@ typedef struct tg_config {
     int32_t n_spots_total;   /* V over all shards (= n_spots on one GPU) */
     int32_t has_density;     /* d given (target_density_enabled, :114) */
     int32_t has_d_source;    /* d_source given (:118) */
-    int32_t fwd_splits;      /* 0 = choose automatically; >0 = number of cell-range splits of the forward GEMM */
+    int32_t fwd_splits;      /* work decomposition of the forward GEMM.  0 = choose automatically; s > 0 = every output tile's cell range cut
+                                into s equal ranges; u < 0 = the (spot tile, contraction step) space of every gene tile cut into -u equal pieces,
+                                whatever the tile boundaries ("stream-K": what the automatic choice uses to fill whole rounds of the chip) */
     int32_t tile_size;       /* 0 = choose automatically; 128 or 256 = GEMM output tile edge (tuning / tests)        */
     int32_t pipeline_bands;  /* 0/1 = sequential schedule (default); 2..16 = cell bands of the opt-in 3-stream pipeline */
     float lambda_g1, lambda_d, lambda_g2, lambda_r, lambda_l1, lambda_l2;

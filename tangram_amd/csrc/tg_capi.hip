@@ -142,25 +142,47 @@ struct TgLayout {
     int smallc;                                       // C <= 32 (clusters mode): the iteration runs on tg_sc_forward / tg_sc_backward
     size_t o_Sa, o_Sx, o_spotpart;
     int fwd_wide;                                     // forward GEMM on 128 x 512 tiles (TgGeoWide)
+    int fwd_units;                                    // workgroups the forward (tile, step) space is cut into (tg_kernels.h, tg_fwd_unit_*)
     int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
-// Number of cell-range splits of the forward GEMM: minimise a small cost model (microseconds, measured on MI355X at cfg2:
-// profiles/r01) of  rounds of workgroups x (steps per workgroup x time per step + fixed cost per workgroup)
-//                 + the write and re-read of the `s` partial copies of Ghat (tg_ghat_reduce streams them at ~1.5 TB/s).
-static int tg_choose_splits(int tiles, int nsteps, int slots, int precision, int tile_edge, size_t part_bytes) {
+// Pieces per gene tile of the forward GEMM (tg_kernels.h: the (spot tile, step) space of one gene tile cut into `units` equal
+// pieces, the same for every gene tile; workgroups = units * nkt): minimise a small cost model (microseconds, measured on
+// MI355X at cfg2: profiles/r01) of
+//     rounds of workgroups x (steps per piece x time per step + fixed cost per segment) + the write and re-read of the partial tiles
+// (tg_ghat_reduce streams them at ~1.5 TB/s) over the candidates: the tiles cut into s = 1, 2, ... equal ranges (no piece crosses
+// a tile), and r = 1, 2, 3 full rounds of the chip's workgroup slots (every CU the same number of steps whatever the tile count:
+// cfg2 has 79 x 2 tiles of 938 steps -- three ranges each were 474 workgroups = 1.85 rounds of 256, 128 pieces x 2 are 1.0).
+static int tg_choose_units(int nvt, int nkt, int nsteps, int slots, int precision, int tile_edge, size_t tile_bytes) {
     double t_step = precision == TG_PREC_F32 ? 7.7 : 2.4;       // 256^2 tile, one contraction step (bf16: 64 elements)
     if (tile_edge != 256) t_step *= 0.5;                        // a quarter of the work on half a CU
-    int best = 1;
+    const long long G = (long long)nvt * nsteps;
+    int best = nvt;
     double best_cost = 1e30;
-    for (int s = 1; s <= 32 && (s == 1 || s <= nsteps / 8); ++s) {   // keep >= 8 contraction steps per workgroup
-        const long rounds = ((long)tiles * s + slots - 1) / slots;
-        const double cost = (double)rounds * ((double)((nsteps + s - 1) / s) * t_step + 8.0) + (double)s * (double)part_bytes * 2.0 / 1.5e6;
-        if (cost < best_cost * 0.995) { best_cost = cost; best = s; }
+    auto consider = [&](long long units, bool aligned) {
+        if (units < 1 || units > G || G / units < (units > nvt ? 8 : 1)) return;        // keep >= 8 contraction steps per piece
+        const long long wgs = units * nkt, rounds = (wgs + slots - 1) / slots, segs = (aligned ? units : units + nvt) * nkt;
+        const double steps = (double)G / (double)units;
+        const double cost = (double)rounds * (steps * t_step + 8.0 * (double)segs / (double)wgs) + (double)segs * (double)tile_bytes * 2.0 / 1.5e6;
+        if (cost < best_cost * 0.995) { best_cost = cost; best = (int)units; }
+    };
+    for (int s = 1; s <= 32; ++s) consider((long long)nvt * s, true);
+    // stream-K pieces: whole rounds of the chip, and a piece length whose start offsets repeat every 8 pieces (units | 8 nvt), so
+    // that the pieces of one XCD walk their tiles in step and share S^T through its L2 (tg_fwd_unit_map)
+    for (int r = 1; r <= 3; ++r) {
+        const long long u = (long long)slots * r / nkt;
+        if (((long long)slots * r) % nkt == 0 && u > 0 && (8LL * nvt) % u == 0 && u % nvt != 0) consider(u, false);
     }
     return best;
+}
+// partial slots per tile that `units` pieces need: the most segments any spot tile is cut into
+static int tg_fwd_slots(int nvt, int nsteps, int units) {
+    const long long G = (long long)nvt * nsteps;
+    int mx = 1;
+    for (int vt = 0; vt < nvt; ++vt) { const int n = tg_fwd_nseg(vt, nsteps, G, units); if (n > mx) mx = n; }
+    return mx;
 }
 
 static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
@@ -247,8 +269,15 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     L->full = (cfg->mode == TG_MODE_CONSTRAINED) || cfg->lambda_r != 0.f || cfg->lambda_l1 != 0.f || cfg->lambda_l2 != 0.f;
     const int nsteps = L->Cp / L->BKE;
     const int slots = 256 * (L->T == 256 ? 1 : 2);
-    L->nsplit = cfg->fwd_splits > 0 ? cfg->fwd_splits : tg_choose_splits(L->nvt * L->nkt, nsteps, slots, cfg->precision, L->T, (size_t)L->Vr * L->Kp * 4);
-    if (L->nsplit > nsteps) L->nsplit = nsteps;
+    {   // forward work decomposition (the forward kernel may run on 128 x 512 tiles: same tile count x area)
+        const int f_nvt = L->fwd_wide ? L->Vr / 128 : L->nvt, f_nkt = L->fwd_wide ? L->Kp / 512 : L->nkt;
+        const int splits = cfg->fwd_splits > nsteps ? nsteps : cfg->fwd_splits;
+        const long long G = (long long)f_nvt * nsteps;
+        L->fwd_units = splits > 0 ? f_nvt * splits
+                     : splits < 0 ? (int)(-(long long)splits > G ? G : -(long long)splits)          // (tests / tuning: that many pieces per gene tile)
+                                  : tg_choose_units(f_nvt, f_nkt, nsteps, slots, cfg->precision, L->T, (size_t)(L->fwd_wide ? 128 * 512 : L->T * L->T) * 4);
+        L->nsplit = tg_fwd_slots(f_nvt, nsteps, L->fwd_units);
+    }
     // cell-band software pipeline (backward GEMM | streaming Adam | next forward GEMM on three streams): single-GPU Mapper only.
     // Opt-in (pipeline_bands >= 2): measured SLOWER than the sequential schedule on MI355X (profiles/r01/run14): the 256^2 GEMM
     // workgroups fill the VGPR file of their CU, so the streaming kernel cannot co-reside and only takes CUs away from the GEMMs.
@@ -258,7 +287,10 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
         if (cfg->pipeline_bands > 1) L->bands = cfg->pipeline_bands;
         if (L->bands > L->nct) L->bands = L->nct;
     }
-    if (L->bands > 1) L->nsplit = L->bands;               // one forward partial per cell band
+    if (L->bands > 1) {                                   // one forward partial per cell band; a whole forward pass (first step, validate,
+        L->nsplit = L->bands;                             // project) cuts every tile into as many equal ranges
+        L->fwd_units = (L->fwd_wide ? L->Vr / 128 : L->nvt) * L->bands;
+    }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += rup(bytes, 256); return o; };
     L->o_Sk = take((size_t)L->Cr * L->Kp * L->ESZ);
@@ -805,8 +837,9 @@ static TgFwdArgs tg_fwd_args(tg_mapper* m, int band, const unsigned char* St_alt
     a.C = L.C; a.V = L.V; a.Vp = L.Vp; a.Vr = L.Vr; a.Kp = L.Kp; a.Cp = L.Cp;
     const int nvt = L.fwd_wide ? L.Vr / 128 : L.nvt, nkt = L.fwd_wide ? L.Kp / 512 : L.nkt;
     a.nkt = nkt; a.nvt = nvt; a.nsplit = L.nsplit; a.nsteps = L.Cp / PR::BKE;
+    a.units = L.fwd_units;
     a.band_index = 0; a.band_step_begin = 0; a.band_step_end = 0;
-    int grid = tg_fwd_grid(nvt, nkt, L.nsplit);
+    int grid = (L.fwd_units % nvt == 0) ? tg_fwd_grid(nvt, nkt, L.fwd_units / nvt) : tg_fwd_units_grid(L.fwd_units, nkt);
     if (band >= 0) {
         int ct0, ct1, c0, c1;
         tg_band_range(L, band, &ct0, &ct1, &c0, &c1);
@@ -839,6 +872,7 @@ static TgGhatReduceArgs tg_ghat_args(tg_mapper* m, bool force_vox) {
     const TgLayout& L = m->L;
     TgGhatReduceArgs a;
     a.Gpart = m->fp(L.o_Gpart); a.nsplit = L.nsplit; a.G = m->fp(L.o_Gp); a.Ghat = m->fp(L.o_Ghat);
+    a.units = L.fwd_units; a.f_tm = L.fwd_wide ? 128 : L.T; a.f_nsteps = L.Cp / L.BKE;
     a.genepart = m->fp(L.o_genepart); a.voxstat = m->fp(L.o_voxstat);
     a.V = L.V; a.Vr = L.Vr; a.Kp = L.Kp; a.K = L.K; a.want_vox = force_vox || (m->cfg.lambda_g2 != 0.f);
     return a;
@@ -1245,7 +1279,7 @@ extern "C" int tg_batch_create(tg_mapper* const* mappers, int n, void* scratch_d
         const tg_mapper* m = mappers[i];
         if (!m || !m->ready) return tg_fail(TG_ERR_STATE, "mapper %d of the batch is not ready", i);
         const TgLayout &A = m->L, &B = m0->L;
-        if (A.C != B.C || A.K != B.K || A.V != B.V || A.prec != B.prec || A.T != B.T || A.nsplit != B.nsplit || A.full != B.full)
+        if (A.C != B.C || A.K != B.K || A.V != B.V || A.prec != B.prec || A.T != B.T || A.nsplit != B.nsplit || A.fwd_units != B.fwd_units || A.full != B.full)
             return tg_fail(TG_ERR_INVALID, "mapper %d differs in shape / precision / terms from mapper 0 (a batch is B mappings of ONE shape)", i);
         if (m->stream != m0->stream) return tg_fail(TG_ERR_INVALID, "all mappers of a batch must be created on the same stream");
         if (m->step != m0->step) return tg_fail(TG_ERR_INVALID, "all mappers of a batch must be at the same step");
@@ -1912,6 +1946,14 @@ extern "C" int tg_debug_fwd_map(int nvt, int nkt, int nsplit, int b, int* vt, in
 }
 // the launch geometry tg_make_layout derives from a configuration: out[0..7] = tile edge, cell tiles, spot tiles, gene tiles,
 // forward splits, forward on 128 x 512 tiles (0/1), cell bands, 0
+// the forward kernel's work decomposition for a configuration: out[0..3] = pieces per gene tile, gene tiles, spot tiles, contraction steps
+extern "C" int tg_debug_fwd_decomposition(const tg_config* cfg, int* out) {
+    TgLayout L;
+    const int rc = tg_make_layout(cfg, &L);
+    if (rc != TG_OK) return rc;
+    out[0] = L.fwd_units; out[1] = L.fwd_wide ? L.Kp / 512 : L.nkt; out[2] = L.fwd_wide ? L.Vr / 128 : L.nvt; out[3] = L.Cp / L.BKE;
+    return TG_OK;
+}
 extern "C" int tg_debug_layout(const tg_config* cfg, int* out) {
     TgLayout L;
     const int rc = tg_make_layout(cfg, &L);

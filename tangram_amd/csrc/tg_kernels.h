@@ -249,10 +249,42 @@ struct TgFwdArgs {
     float* Gpart;            // [nsplit][Vr][Kp]
     int C, V, Vp, Vr, Kp, Cp;
     int nkt;                 // gene tiles (Kp / TN)
-    int nvt, nsplit;         // spot tiles, cell-range splits
+    int nvt, nsplit;         // spot tiles, partial slots per tile in Gpart (>= the segments any tile is cut into)
     int nsteps;              // Cp / BKE
+    int units;               // pieces the (spot tile, step) space of ONE gene tile is cut into (tg_fwd_unit_* below); grid: units * nkt
     int band_index, band_step_begin, band_step_end;   // band mode (band_step_end > 0): ONE cell range -> partial `band_index`
 };
+// Work decomposition of the forward GEMM ("stream-K").  For ONE gene tile kt, the spot tiles vt = 0 .. nvt-1, each `nsteps`
+// contraction steps long, form a step space of G = nvt * nsteps steps, cut into `units` equal pieces: piece j owns the global
+// steps [j G / units, (j + 1) G / units) -- a tail of one spot tile and a head of the next, i.e. one or two SEGMENTS (more when a
+// piece is longer than a tile).  Every gene tile is cut at the SAME places, and workgroup (j, kt) sits next to (j, kt + 1): the
+// nkt workgroups that read one range of an M panel run side by side on one XCD and share it through that XCD's L2 (cutting the
+// tiles of all gene tiles as ONE step space put them at different steps at any moment: the M panels were re-read from HBM,
+// forward +3 % split-bf16, +50 % bf16 on four gene tiles -- profiles/r04/run5_streamk).  With units * nkt = a multiple of the
+// CUs every CU gets the same number of steps whatever the tile count (round 3 cut every tile into nsplit equal ranges: 474
+// workgroups at cfg2 = 1.85 rounds of 256, 7 % of the chip idle).  Segment i of spot tile vt (i = j - first piece touching vt) is
+// written to partial slot i; tg_ghat_reduce sums the tg_fwd_nseg(vt) slots of a tile in slot order: the sum order is a function
+// of the shape alone (bit-reproducible) and the same for every gene column.  units = nvt * s reproduces s equal ranges per tile.
+TG_HD long long tg_fwd_unit_begin(long long j, long long G, int units) { return j * G / units; }
+TG_HD int tg_fwd_unit_of(long long x, long long G, int units) { return (int)(((x + 1) * units - 1) / G); }       // piece owning global step x
+TG_HD int tg_fwd_nseg(int vt, int nsteps, long long G, int units) {
+    return tg_fwd_unit_of((long long)(vt + 1) * nsteps - 1, G, units) - tg_fwd_unit_of((long long)vt * nsteps, G, units) + 1;
+}
+// Workgroup b -> (piece j, gene tile kt).  What the workgroups running side by side on one XCD (b % 8) should share through its
+// 4 MB L2 besides the M panel: the S^T tile of their contraction steps -- which they only do when they are at the SAME step of
+// their tiles at the same time (an XCD's 32 workgroups turn its L2 over every ~2 steps).
+//   pieces that do not cross tiles (units = nvt * s): the round-3 map -- an XCD holds spot tiles vt = x, x + 8, ... of ONE range;
+//   stream-K pieces: XCD x takes the pieces j = x, x + 8, x + 16, ...  Their start offsets inside a tile, j L mod nsteps with
+//   L = nvt nsteps / units, coincide exactly when units divides 8 nvt (cfg2: 80 spot tiles, 128 pieces, L = 5/8 of a tile): that
+//   is the shape of stream-K decompositions tg_choose_units considers.  (Contiguous ranges of pieces per XCD: the pieces of an
+//   XCD are then at 16 different offsets and S^T comes out of the MALL instead: forward 1.32 -> 1.29 ms instead of -> 1.23.)
+TG_HD int tg_fwd_units_grid(int units, int nkt) { return 8 * ((units + 7) / 8) * nkt; }
+TG_HD bool tg_fwd_unit_map(int b, int units, int nkt, int& j, int& kt) {
+    const int x = b & 7, idx = b >> 3;
+    j = x + 8 * (idx / nkt);
+    kt = idx % nkt;
+    return j < units;
+}
 // grid of the forward kernel: the nkt gene tiles that share one M panel (same spot tile, same cell range) sit
 // next to each other on ONE XCD; the panels in flight on an XCD belong to the same cell range and share S^T.
 TG_HD int tg_fwd_grid(int nvt, int nkt, int nsplit) { return ((nvt * nsplit + 7) / 8) * 8 * nkt; }
@@ -266,19 +298,45 @@ TG_HD bool tg_fwd_map(int b, int nvt, int nkt, int nsplit, int& vt, int& kt, int
 }
 
 template <class PR, class GE>
+TG_DEV void tg_fwd_segment(const TgFwdArgs& a, int vt, int kt, int part_slot, int s_begin, int s_end);
+
+template <class PR, class GE>
 TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
+    if (a.band_step_end > 0) {                                 // band mode: one workgroup per tile, ONE cell range -> partial `band_index`
+        int vt, kt, split;
+        if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, 1, vt, kt, split)) return;
+        tg_fwd_segment<PR, GE>(a, vt, kt, a.band_index, a.band_step_begin, a.band_step_end);
+        return;
+    }
+    int j, kt;
+    if (a.units % a.nvt == 0) {                                // pieces inside tiles: the round-3 map (range-major over the XCDs)
+        int vt, split;
+        const int s = a.units / a.nvt;
+        if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, s, vt, kt, split)) return;
+        j = vt * s + split;
+    } else if (!tg_fwd_unit_map(blockIdx.x, a.units, a.nkt, j, kt)) return;
+    const long long G = (long long)a.nvt * a.nsteps;
+    const long long g1 = tg_fwd_unit_begin(j + 1, G, a.units);
+    bool first = true;
+    for (long long g = tg_fwd_unit_begin(j, G, a.units); g < g1;) {
+        const int vt = (int)(g / a.nsteps), s_begin = (int)(g - (long long)vt * a.nsteps);
+        const int len = (g1 - g < a.nsteps - s_begin) ? (int)(g1 - g) : a.nsteps - s_begin;
+        if (!first) __syncthreads();                           // the LDS stages of the previous segment have been read out
+        first = false;
+        tg_fwd_segment<PR, GE>(a, vt, kt, j - tg_fwd_unit_of((long long)vt * a.nsteps, G, a.units), s_begin, s_begin + len);
+        g += len;
+    }
+}
+
+// one segment: the contraction steps [s_begin, s_end) of tile (vt, kt) -> partial slot `slot`
+template <class PR, class GE>
+TG_DEV void tg_fwd_segment(const TgFwdArgs& a, int vt, int kt, int part_slot, int s_begin, int s_end) {
     TG_LDS_DECL;
     u32x4* lds = (u32x4*)tg_lds;
     const int t = threadIdx.x, lane = t & 63, wave = tg_uniform(t >> 6);
     const int wm = wave / GE::WN, wn = wave % GE::WN;
-    int vt, kt, split;
-    const bool band = a.band_step_end > 0;
-    if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, band ? 1 : a.nsplit, vt, kt, split)) return;
-    const int nsplit = a.nsplit;
     const int v0 = vt * GE::TM, k0 = kt * GE::TN;
-    if (band) split = a.band_index;
-    const int s_begin = band ? a.band_step_begin : (int)(((long long)a.nsteps * split) / nsplit);
-    const int s_end = band ? a.band_step_end : (int)(((long long)a.nsteps * (split + 1)) / nsplit);
+    const int split = part_slot;
 
     f32x4 acc[GE::FM][GE::FN];
 #pragma unroll
@@ -453,6 +511,7 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
 
 struct TgGhatReduceArgs {
     const float* Gpart; int nsplit;
+    int units, f_tm, f_nsteps;  // the forward kernel's decomposition (tg_fwd_nseg): slots to sum per spot tile
     const float* G;            // [Vr][Kp] fp32, zero padded
     float* Ghat;               // [Vr][Kp]
     float* genepart;           // [nrb][2][Kp]  (dot, |Ghat|^2)
@@ -473,6 +532,8 @@ TG_DEV void tg_ghat_reduce_body(const TgGhatReduceArgs& a) {
     const bool kok = k < a.Kp;
     f32x4 gd = {0, 0, 0, 0}, gn = {0, 0, 0, 0};
     float vd[TG_RB / 4], vn[TG_RB / 4];
+    // partial slots of the forward tile this lane's elements belong to (the 16 spots of the block lie in one spot tile)
+    const int nseg = tg_fwd_nseg(rb * TG_RB / a.f_tm, a.f_nsteps, (long long)(a.Vr / a.f_tm) * a.f_nsteps, a.units);
 #pragma unroll
     for (int i = 0; i < TG_RB / 4; ++i) {
         vd[i] = vn[i] = 0.f;
@@ -480,7 +541,7 @@ TG_DEV void tg_ghat_reduce_body(const TgGhatReduceArgs& a) {
         if (kok && v < a.V) {
             const size_t off = (size_t)v * a.Kp + k;
             f32x4 s = *(const f32x4*)(a.Gpart + off);
-            for (int p = 1; p < a.nsplit; ++p) s += *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
+            for (int p = 1; p < nseg; ++p) s += *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
             *(f32x4*)(a.Ghat + off) = s;
             const f32x4 g = *(const f32x4*)(a.G + off);
             gd += s * g;

@@ -444,3 +444,29 @@ def test_emulated_project_genes_from_csr(sim):
         np.testing.assert_array_equal(out, e.project_genes(dense).numpy())
     with pytest.raises(ValueError):
         e.project_genes(sp.csr_matrix(dense[:-1]))
+
+
+@pytest.mark.parametrize("units", [1, 2, 5, 7, 13, 29])
+def test_emulated_forward_work_units_across_tile_boundaries(sim, units):
+    """The forward GEMM's (spot tile, contraction step) space cut into `units` equal pieces per gene tile whatever the tile boundaries
+    (fwd_splits < 0): 3 spot tiles of 128 x 11 steps = 33 global steps (x 2 gene tiles), so 5 / 7 / 13 / 29 pieces start and end in
+    the middle of tiles, a piece spans up to three of them, a tile is summed from up to 11 partial slots.  Every decomposition: the oracle's trajectory within the fp32
+    tolerance, and the same projection as the one-unit-per-tile run up to summation order."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    C, K, V = 340, 200, 300                          # 3 spot tiles x 2 gene tiles (201 gene columns), 11 steps of 32 cells
+    data = orc.make_synthetic(C, K, V, seed=17)
+    M0 = orc.reference_init_M(C, V, 4)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=128,
+                        fwd_splits=-units)
+    h = e.new_history(3)
+    e.step(3, 0.1, h)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(3, 0.1)
+    assert np.abs(h.numpy()[:, 1] - np.array(ho["main_loss"])).max() <= 1e-5
+    assert np.abs(h.numpy()[:, 0] - np.array(ho["total_loss"])).max() <= 1e-5
+    assert np.abs(e.result().numpy() - Po).max() <= 2e-4
+    Gh = e.project().numpy().astype(np.float64)
+    ref = Po.T @ data["S"].astype(np.float64)
+    assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= 1e-4
