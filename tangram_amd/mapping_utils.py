@@ -154,10 +154,14 @@ def map_cells_to_space(
     keep_mapper=False,
     distributed=False,
     group=None,
+    s_exact=False,
+    init="reference",
 ):
     """Map single cell data (`adata_sc`) on spatial data (`adata_sp`); see the reference docstring (:169-203).
 
-    Extra keywords: `gemm_precision` (tangram_amd.mapping_optimizer); `distributed=True` (+ optional `group`): shard the spots over
+    Extra keywords: `s_exact="auto"`: two matrix-core products per element instead of three when the training-gene matrix of
+    `adata_sc` is bf16-exact (raw counts), same values; `init="device"`: initial logits from the library's device generator
+    instead of NumPy's stream (both opt-in, see tangram_amd.mapping_optimizer.Mapper); `gemm_precision` (tangram_amd.mapping_optimizer); `distributed=True` (+ optional `group`): shard the spots over
     the ranks of an initialised torch.distributed process group -- opt-in, the same call on every rank, every rank gets the full
     result (tangram_amd.mapping_optimizer); `keep_mapper=True` leaves the trained mapper on the
     result as `adata_map._tangram_amd_mapper` so that `tangram_amd.project_genes(..., mapper=adata_map._tangram_amd_mapper)`
@@ -253,7 +257,7 @@ def map_cells_to_space(
         logging.info("Begin training with {} genes and {} density_prior in {} mode...".format(
             len(training_genes), d_str, mode))
         mapper = mo.Mapper(S=S, G=G, d=d, device=device, random_state=random_state, gemm_precision=gemm_precision,
-                           distributed=distributed, group=group, **hyperparameters)   # :355-357
+                           distributed=distributed, group=group, s_exact=s_exact, init=init, **hyperparameters)   # :355-357
         mapping_matrix, training_history = mapper.train(
             learning_rate=learning_rate, num_epochs=num_epochs, print_each=print_each)   # :361-363
     else:
@@ -264,7 +268,7 @@ def map_cells_to_space(
         logging.info("Begin training with {} genes and {} density_prior in {} mode...".format(
             len(training_genes), d_str, mode))
         mapper = mo.MapperConstrained(S=S, G=G, d=d, device=device, random_state=random_state,
-                                      gemm_precision=gemm_precision, distributed=distributed, group=group,
+                                      gemm_precision=gemm_precision, distributed=distributed, group=group, s_exact=s_exact, init=init,
                                       **hyperparameters)                      # :383-385
         mapping_matrix, F_out, training_history = mapper.train(
             learning_rate=learning_rate, num_epochs=num_epochs, print_each=print_each)   # :387-389
