@@ -540,8 +540,24 @@ TG_DEV void tg_ghat_reduce_body(const TgGhatReduceArgs& a) {
         const int v = vbeg + i;
         if (kok && v < a.V) {
             const size_t off = (size_t)v * a.Kp + k;
-            f32x4 s = *(const f32x4*)(a.Gpart + off);
-            for (int p = 1; p < nseg; ++p) s += *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
+            // the partial slots of this element, summed in slot order; requested four or eight at a time (a thin spot shard has 12
+            // slots and ~1 workgroup per CU: one dependent load after the other made this kernel latency-bound, 24 us for 73 MB)
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            auto sum_slots = [&](auto width) {
+                constexpr int W = decltype(width)::value;
+                for (int p0 = 0; p0 < nseg; p0 += W) {
+                    f32x4 part[W];
+#pragma unroll
+                    for (int q2 = 0; q2 < W; ++q2) {
+                        const int p = (p0 + q2 < nseg) ? p0 + q2 : nseg - 1;      // (clamped: in bounds; the value is dropped below)
+                        part[q2] = *(const f32x4*)(a.Gpart + (size_t)p * a.Vr * a.Kp + off);
+                    }
+#pragma unroll
+                    for (int q2 = 0; q2 < W; ++q2)
+                        if (p0 + q2 < nseg) s = (p0 + q2 == 0) ? part[q2] : s + part[q2];
+                }
+            };
+            if (nseg <= 4) sum_slots(std::integral_constant<int, 4>()); else sum_slots(std::integral_constant<int, 8>());
             *(f32x4*)(a.Ghat + off) = s;
             const f32x4 g = *(const f32x4*)(a.G + off);
             gd += s * g;

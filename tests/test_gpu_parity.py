@@ -695,3 +695,26 @@ def test_cross_val_batched_on_gpu():
     assert abs(cv["avg_train_score"] - np.mean(tr_ref)) < 1e-7            # the folds' trainings are the same bits
     np.testing.assert_allclose(ad_ge.var["test_score"].to_numpy(), t_ref, atol=5e-6)
     assert ad_ge.X.shape == (700, 11) and len(df) == 11
+
+
+def test_device_initialiser_on_the_gpu():
+    """tg_init_logits_normal on the hardware (`Mapper(init="device")`): any block of columns equals the same columns of the full
+    plane bit for bit -- what makes a spot shard's logits independent of the number of ranks --, N(0, 1) moments over 4e6 draws,
+    reproducible, and a Mapper started from it trains (the CPU suite checks the same on the emulator)."""
+    from tangram_amd.device_init import device_normal
+    from tangram_amd.mapping_optimizer import Mapper
+    from oracle import tangram_oracle as orc
+    C, V = 2000, 2003
+    full = device_normal(C, V, DEV, seed=42)
+    assert torch.equal(full, device_normal(C, V, DEV, seed=42))
+    for lo, hi in [(0, 1000), (1000, 2003), (777, 778), (5, 1999)]:
+        assert torch.equal(device_normal(C, hi - lo, DEV, seed=42, col0=lo, n_cols_total=V), full[:, lo:hi])
+    x = full.double()
+    assert abs(float(x.mean())) < 3e-3 and abs(float(x.std()) - 1.0) < 3e-3 and abs(float((x ** 3).mean())) < 1e-2 and abs(float((x ** 4).mean()) - 3.0) < 3e-2
+    assert float(x.abs().max()) < 6.5 and bool(torch.isfinite(full).all())
+    assert float((device_normal(C, V, DEV, seed=43) != full).float().mean()) > 0.99
+    data = orc.make_synthetic(500, 60, 300, seed=1)
+    kw = dict(d=data["d"], lambda_d=1, lambda_g1=1, device=DEV)
+    P1, h1 = Mapper(data["S"], data["G"], random_state=9, init="device", **kw).train(8, print_each=None)
+    P2, _ = Mapper(data["S"], data["G"], random_state=9, init="device", **kw).train(8, print_each=None)
+    assert np.array_equal(P1, P2) and h1["main_loss"][-1] > h1["main_loss"][0]
