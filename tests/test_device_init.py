@@ -127,3 +127,51 @@ def test_sharded_device_init_never_holds_the_plane_on_the_host(sim, tmp_path):
         assert int(z["peak"]) < 0.8 * plane, (int(z["peak"]), plane)
         covered += hi - lo
     assert covered == V
+
+
+def _worker_c(rank, world, port, sim_path, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tangram_amd import _capi
+        _capi._install_library_for_tests(sim_path)
+        from oracle import tangram_oracle as orc
+        from tangram_amd.mapping_optimizer import Mapper, MapperConstrained
+        C, K, V = 160, 40, 210
+        data = orc.make_synthetic(C, K, V, seed=12)
+        # MapperConstrained on shards from the device generator (M block by block, the replicated filter F from its own stream),
+        # local result; and the two-product path (count data: bf16-exact S) on shards
+        mc = MapperConstrained(data["S"], data["G"], data["d"], device="cpu", gemm_precision="bf16x3", random_state=21, target_count=90,
+                               distributed=True, init="device", gather_result=False, s_exact="auto")
+        Pc, Fc, hc = mc.train(4, print_each=None)
+        m = Mapper(data["S"], data["G"], d=data["d"], lambda_d=1, lambda_g1=1, device="cpu", gemm_precision="bf16x3", random_state=21,
+                   distributed=True, init="device", s_exact="auto")
+        P, h = m.train(4, print_each=None)
+        np.savez(os.path.join(outdir, f"c{rank}.npz"), Pc=Pc, Fc=Fc, lo=mc.spot_range[0], hi=mc.spot_range[1], P=P,
+                 main=np.array(h["main_loss"]), eff=np.array([m._engine.effective_precision.startswith("bf16x3 (S exact"),
+                                                              mc._engine.effective_precision.startswith("bf16x3 (S exact")]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_constrained_device_init_and_two_product_path(sim, tmp_path):
+    mp.spawn(_worker_c, args=(2, _free_port(), sim, str(tmp_path)), nprocs=2, join=True)
+    from oracle import tangram_oracle as orc
+    from tangram_amd.mapping_optimizer import Mapper, MapperConstrained
+    C, K, V = 160, 40, 210
+    data = orc.make_synthetic(C, K, V, seed=12)
+    Pc, Fc, _ = MapperConstrained(data["S"], data["G"], data["d"], device="cpu", gemm_precision="bf16x3", random_state=21, target_count=90,
+                                  init="device").train(4, print_each=None)                      # one process, general path
+    P, h = Mapper(data["S"], data["G"], d=data["d"], lambda_d=1, lambda_g1=1, device="cpu", gemm_precision="bf16x3", random_state=21,
+                  init="device").train(4, print_each=None)
+    z0, z1 = np.load(tmp_path / "c0.npz"), np.load(tmp_path / "c1.npz")
+    assert z0["eff"].all() and z1["eff"].all()                       # every rank found S exact and took the two-product path
+    np.testing.assert_array_equal(z0["P"], z1["P"])                  # gathered result: identical on both ranks
+    np.testing.assert_allclose(z0["P"], P, atol=2e-6)                # = the unsharded general-path run up to summation order
+    np.testing.assert_allclose(z0["main"], np.array(h["main_loss"]), atol=2e-6)
+    for z in (z0, z1):
+        lo, hi = int(z["lo"]), int(z["hi"])
+        np.testing.assert_allclose(z["Pc"], Pc[:, lo:hi], atol=2e-6)
+        np.testing.assert_allclose(z["Fc"], Fc, atol=2e-6)
+    assert int(z0["hi"]) == int(z1["lo"]) and int(z1["hi"]) == V
