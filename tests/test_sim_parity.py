@@ -470,3 +470,29 @@ def test_emulated_forward_work_units_across_tile_boundaries(sim, units):
     Gh = e.project().numpy().astype(np.float64)
     ref = Po.T @ data["S"].astype(np.float64)
     assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= 1e-4
+
+
+@pytest.mark.parametrize("s_exact", [False, "auto"])
+def test_emulated_wide_forward_geometry(sim, s_exact):
+    """The split-bf16 forward on 128 x 512 tiles (tile_size = 256 and a padded gene count that is a multiple of 512: waves 0-3 stage
+    the softmax operand, waves 4-7 only multiply) on the emulator -- the small CPU cases otherwise never take this geometry.
+    Against the fp64 oracle, general and two-product path, ragged spots / genes / cells."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd.engine import HipMapperEngine
+    import ctypes as ct
+    C, K, V = 210, 300, 150
+    data = orc.make_synthetic(C, K, V, seed=31)
+    M0 = orc.reference_init_M(C, V, 8)
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="bf16x3", lambdas=lam, tile_size=256, s_exact=s_exact)
+    geo = (ct.c_int * 8)()
+    assert e._lib.tg_debug_layout(ct.byref(e.cfg), geo) == 0 and geo[5] == 1, "this shape must take the wide forward geometry"
+    h = e.new_history(3)
+    e.step(3, 0.1, h)
+    o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+    Po, ho = o.train(3, 0.1)
+    assert np.abs(h.numpy()[:, 1] - np.array(ho["main_loss"])).max() <= 1e-5 and np.abs(h.numpy()[:, 0] - np.array(ho["total_loss"])).max() <= 1e-5
+    assert np.abs(e.result().numpy() - Po).max() <= 2e-4
+    Gh = e.project().numpy().astype(np.float64)
+    ref = Po.T @ data["S"].astype(np.float64)
+    assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= 1e-4
