@@ -1944,8 +1944,6 @@ extern "C" int tg_debug_fwd_map(int nvt, int nkt, int nsplit, int b, int* vt, in
     if (b < 0) return tg_fwd_grid(nvt, nkt, nsplit);
     return tg_fwd_map(b, nvt, nkt, nsplit, *vt, *kt, *split) ? 1 : 0;
 }
-// the launch geometry tg_make_layout derives from a configuration: out[0..7] = tile edge, cell tiles, spot tiles, gene tiles,
-// forward splits, forward on 128 x 512 tiles (0/1), cell bands, 0
 // the forward kernel's work decomposition for a configuration: out[0..3] = pieces per gene tile, gene tiles, spot tiles, contraction steps
 extern "C" int tg_debug_fwd_decomposition(const tg_config* cfg, int* out) {
     TgLayout L;
@@ -1954,6 +1952,43 @@ extern "C" int tg_debug_fwd_decomposition(const tg_config* cfg, int* out) {
     out[0] = L.fwd_units; out[1] = L.fwd_wide ? L.Kp / 512 : L.nkt; out[2] = L.fwd_wide ? L.Vr / 128 : L.nvt; out[3] = L.Cp / L.BKE;
     return TG_OK;
 }
+// Host replay of the forward launch of a configuration (no device needed): every workgroup of the grid walks its segments through the
+// kernel's own tg_fwd_walk; checked: each (spot tile, gene tile, step) is taken exactly once, a tile's partial slots are 0 .. nseg - 1
+// (what tg_ghat_reduce sums), each written once, nseg <= the slots the layout reserves.  out[0..5] = grid, workgroups with work,
+// fewest / most steps of a working workgroup, most segments of a workgroup, partial slots reserved.
+extern "C" int tg_debug_fwd_cover(const tg_config* cfg, long long* out) {
+    TgLayout L;
+    const int rc = tg_make_layout(cfg, &L);
+    if (rc != TG_OK) return rc;
+    if (L.smallc || L.bands > 1) return tg_fail(TG_ERR_INVALID, "tg_debug_fwd_cover: this configuration does not launch the decomposed forward GEMM");
+    const int nvt = L.fwd_wide ? L.Vr / 128 : L.nvt, nkt = L.fwd_wide ? L.Kp / 512 : L.nkt, nsteps = L.Cp / L.BKE, units = L.fwd_units;
+    const int grid = (units % nvt == 0) ? tg_fwd_grid(nvt, nkt, units / nvt) : tg_fwd_units_grid(units, nkt);
+    const long long G = (long long)nvt * nsteps;
+    std::vector<unsigned char> taken((size_t)nvt * nkt * nsteps, 0), slot((size_t)nvt * nkt * L.nsplit, 0);
+    long long working = 0, lo = -1, hi = 0, most_seg = 0;
+    const char* bad = nullptr;
+    for (int b = 0; b < grid; ++b) {
+        long long steps = 0, segs = 0;
+        tg_fwd_walk(b, nvt, nkt, nsteps, units, [&](int vt, int kt, int part_slot, int s_begin, int s_end) {
+            if (vt < 0 || vt >= nvt || kt < 0 || kt >= nkt || s_begin < 0 || s_end > nsteps || s_begin >= s_end) { bad = "segment out of range"; return; }
+            if (part_slot < 0 || part_slot >= L.nsplit || part_slot >= tg_fwd_nseg(vt, nsteps, G, units)) { bad = "partial slot out of range"; return; }
+            if (slot[((size_t)vt * nkt + kt) * L.nsplit + part_slot]++) bad = "partial slot written twice";
+            for (int st = s_begin; st < s_end; ++st) if (taken[((size_t)vt * nkt + kt) * nsteps + st]++) bad = "step taken twice";
+            steps += s_end - s_begin; ++segs;
+        });
+        if (segs) { ++working; if (lo < 0 || steps < lo) lo = steps; if (steps > hi) hi = steps; if (segs > most_seg) most_seg = segs; }
+    }
+    for (size_t i = 0; i < taken.size() && !bad; ++i) if (taken[i] != 1) bad = "step not taken";
+    for (int vt = 0; vt < nvt && !bad; ++vt)
+        for (int kt = 0; kt < nkt; ++kt)
+            for (int i = 0; i < L.nsplit; ++i)
+                if ((slot[((size_t)vt * nkt + kt) * L.nsplit + i] != 0) != (i < tg_fwd_nseg(vt, nsteps, G, units))) bad = "partial slots are not 0 .. nseg - 1";
+    if (bad) return tg_fail(TG_ERR_INVALID, "tg_debug_fwd_cover: %s (nvt %d nkt %d nsteps %d units %d)", bad, nvt, nkt, nsteps, units);
+    out[0] = grid; out[1] = working; out[2] = lo; out[3] = hi; out[4] = most_seg; out[5] = L.nsplit;
+    return TG_OK;
+}
+// the launch geometry tg_make_layout derives from a configuration: out[0..7] = tile edge, cell tiles, spot tiles, gene tiles,
+// forward splits, forward on 128 x 512 tiles (0/1), cell bands, clusters-mode kernels (0/1)
 extern "C" int tg_debug_layout(const tg_config* cfg, int* out) {
     TgLayout L;
     const int rc = tg_make_layout(cfg, &L);

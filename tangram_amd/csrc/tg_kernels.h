@@ -297,6 +297,28 @@ TG_HD bool tg_fwd_map(int b, int nvt, int nkt, int nsplit, int& vt, int& kt, int
     return unit < nvt * nsplit;
 }
 
+// The segments of workgroup b, in order: f(spot tile, gene tile, partial slot, first step, one past the last step).  Shared by the
+// kernel and by tg_debug_fwd_cover (host), which replays every workgroup of a grid and checks that each (tile, step) is taken
+// exactly once and each tile's partial slots 0 .. nseg - 1 are each written once.
+template <class F>
+TG_HD void tg_fwd_walk(int b, int nvt, int nkt, int nsteps, int units, F&& f) {
+    int j, kt;
+    if (units % nvt == 0) {                                    // pieces inside tiles: the round-3 map (range-major over the XCDs)
+        int vt, split;
+        const int s = units / nvt;
+        if (!tg_fwd_map(b, nvt, nkt, s, vt, kt, split)) return;
+        j = vt * s + split;
+    } else if (!tg_fwd_unit_map(b, units, nkt, j, kt)) return;
+    const long long G = (long long)nvt * nsteps;
+    const long long g1 = tg_fwd_unit_begin(j + 1, G, units);
+    for (long long g = tg_fwd_unit_begin(j, G, units); g < g1;) {
+        const int vt = (int)(g / nsteps), s_begin = (int)(g - (long long)vt * nsteps);
+        const int len = (g1 - g < nsteps - s_begin) ? (int)(g1 - g) : nsteps - s_begin;
+        f(vt, kt, j - tg_fwd_unit_of((long long)vt * nsteps, G, units), s_begin, s_begin + len);
+        g += len;
+    }
+}
+
 template <class PR, class GE>
 TG_DEV void tg_fwd_segment(const TgFwdArgs& a, int vt, int kt, int part_slot, int s_begin, int s_end);
 
@@ -308,24 +330,12 @@ TG_DEV void tg_fwd_body(const TgFwdArgs& a) {
         tg_fwd_segment<PR, GE>(a, vt, kt, a.band_index, a.band_step_begin, a.band_step_end);
         return;
     }
-    int j, kt;
-    if (a.units % a.nvt == 0) {                                // pieces inside tiles: the round-3 map (range-major over the XCDs)
-        int vt, split;
-        const int s = a.units / a.nvt;
-        if (!tg_fwd_map(blockIdx.x, a.nvt, a.nkt, s, vt, kt, split)) return;
-        j = vt * s + split;
-    } else if (!tg_fwd_unit_map(blockIdx.x, a.units, a.nkt, j, kt)) return;
-    const long long G = (long long)a.nvt * a.nsteps;
-    const long long g1 = tg_fwd_unit_begin(j + 1, G, a.units);
     bool first = true;
-    for (long long g = tg_fwd_unit_begin(j, G, a.units); g < g1;) {
-        const int vt = (int)(g / a.nsteps), s_begin = (int)(g - (long long)vt * a.nsteps);
-        const int len = (g1 - g < a.nsteps - s_begin) ? (int)(g1 - g) : a.nsteps - s_begin;
+    tg_fwd_walk(blockIdx.x, a.nvt, a.nkt, a.nsteps, a.units, [&](int vt, int kt, int part_slot, int s_begin, int s_end) {
         if (!first) __syncthreads();                           // the LDS stages of the previous segment have been read out
         first = false;
-        tg_fwd_segment<PR, GE>(a, vt, kt, j - tg_fwd_unit_of((long long)vt * a.nsteps, G, a.units), s_begin, s_begin + len);
-        g += len;
-    }
+        tg_fwd_segment<PR, GE>(a, vt, kt, part_slot, s_begin, s_end);
+    });
 }
 
 // one segment: the contraction steps [s_begin, s_end) of tile (vt, kt) -> partial slot `slot`

@@ -3,6 +3,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -139,6 +140,65 @@ def test_forward_grid_map_is_a_bijection(nvt, nkt, nsplit):
             assert key not in seen and a.value < nvt and b_.value < nkt and c.value < nsplit
             seen.add(key)
     assert len(seen) == nvt * nkt * nsplit
+
+
+def _fwd_cover(lib, C, K, V, prec, v_total=0, ranks=0, tile=0, fwd_splits=0):
+    from tangram_amd import _capi
+    cfg = _capi.TgConfig()
+    cfg.abi_version = _capi.TG_ABI_VERSION
+    cfg.n_cells, cfg.n_genes, cfg.n_spots, cfg.n_spots_total, cfg.n_ranks = C, K, V, v_total, ranks
+    cfg.lambda_g1, cfg.has_density, cfg.lambda_d, cfg.precision, cfg.tile_size, cfg.fwd_splits = 1.0, 1, 1.0, prec, tile, fwd_splits
+    out = (ctypes.c_longlong * 6)()
+    rc = lib.tg_debug_fwd_cover(ctypes.byref(cfg), out)
+    assert rc == 0, lib.tg_last_error().decode()
+    dec = (ctypes.c_int * 4)()
+    assert lib.tg_debug_fwd_decomposition(ctypes.byref(cfg), dec) == 0
+    return list(out), list(dec)
+
+
+def test_forward_decomposition_covers_the_baseline_shapes():
+    """Host replay of the forward launch (tg_debug_fwd_cover walks every workgroup through the kernel's own tg_fwd_walk): at the
+    BASELINE shapes, which the CPU emulator cannot run, every (spot tile, gene tile, contraction step) is taken exactly once and
+    the partial slots of every tile are the ones tg_ghat_reduce sums.  cfg2 in split-bf16 must be the stream-K decomposition
+    (128 pieces x 2 wide gene tiles = one exactly full round of 256 CUs, every workgroup the same number of steps)."""
+    from tangram_amd import _build
+    lib = ctypes.CDLL(_build.build())
+    lib.tg_last_error.restype = ctypes.c_char_p
+    (grid, working, lo, hi, most_seg, slots), (units, nkt, nvt, nsteps) = _fwd_cover(lib, 30000, 1000, 10000, 2)
+    assert (units, nkt, nvt) == (128, 2, 80) and units % nvt != 0 and (8 * nvt) % units == 0
+    assert grid == working == 256 and hi - lo <= 1 and lo * units <= nvt * nsteps <= hi * units and most_seg == 2 and slots == 3
+    # (a piece is 5/8 of a tile: a workgroup touches two tiles, a tile is summed from up to three partial slots)
+    for shape in [(30000, 1000, 10000, 1), (30000, 1000, 10000, 0), (200000, 2000, 50000, 1), (200000, 2000, 50000, 2),
+                  (30000, 1000, 1250, 2, 10000, 8), (200000, 2000, 6250, 1, 50000, 8), (26431, 249, 9852, 2), (4200, 1000, 1500, 2)]:
+        (grid, working, lo, hi, most_seg, slots), (units, nkt, nvt, nsteps) = _fwd_cover(lib, *shape)
+        assert working == units * nkt <= grid and lo >= 1 and slots >= 1
+        if units % nvt:                                  # stream-K pieces: equal shares of the step space
+            assert hi - lo <= 1
+        if len(shape) > 4:                               # spot shards keep whole ranges of tiles (S^T shared through L2, DESIGN 4)
+            assert units % nvt == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_forward_decomposition_covers_random_shapes(seed):
+    """The same replay over random shapes, tile sizes and FORCED piece counts (fwd_splits < 0: pieces that start and end anywhere,
+    longer or shorter than a tile), incl. piece counts that do not divide anything."""
+    from tangram_amd import _build
+    lib = ctypes.CDLL(_build.build())
+    lib.tg_last_error.restype = ctypes.c_char_p
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(40):
+        C, K, V = int(rng.integers(1, 5000)), int(rng.integers(1, 1400)), int(rng.integers(1, 6000))
+        if C <= 32:
+            C += 33                                      # (clusters-mode shapes do not launch this kernel)
+        prec, tile = int(rng.integers(0, 3)), int(rng.choice([0, 128, 256]))
+        forced = int(rng.integers(0, 3))
+        fwd_splits = 0 if forced == 0 else (int(rng.integers(1, 9)) if forced == 1 else -int(rng.integers(1, 200)))
+        (grid, working, lo, hi, most_seg, slots), (units, nkt, nvt, nsteps) = _fwd_cover(lib, C, K, V, prec, tile=tile, fwd_splits=fwd_splits)
+        assert working == units * nkt <= grid and most_seg >= 1 and slots >= 1
+        if fwd_splits < 0:
+            assert units == min(-fwd_splits, nvt * nsteps)
+        elif fwd_splits > 0:
+            assert units == nvt * min(fwd_splits, nsteps)
 
 
 def test_launch_geometry_of_the_baseline_shapes():
