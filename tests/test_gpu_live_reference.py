@@ -161,6 +161,27 @@ FULL_BOUNDS = {"bf16x3": dict(frac_moved=1e-6, rel_P=1e-5, F=1e-5), "fp32": dict
                "bf16": dict(frac_moved=1e-4, rel_P=2e-3, F=2e-3)}
 
 
+def test_full_size_public_mapper_from_the_seed(ref_mo):
+    """The drop-in class itself at the full cfg2 shape: `tangram_amd.mapping_optimizer.Mapper(..., random_state=42)` draws its own
+    3e8 initial logits (the threaded NumPy-stream helper, host_rng.py) and trains with the default precision; the mapping and the
+    history dict against the reference's from the same seed (an initialiser that differed anywhere would show up at order 1)."""
+    from tangram_amd.mapping_optimizer import Mapper
+    from tests import parity_common as pc
+    r = _full_reference(ref_mo, "cfg2")
+    data = r["data"]
+    m = Mapper(S=data["S"], G=data["G"], d=data["d"], device="cuda:0", random_state=42, **FULL_CASES["cfg2"][1])
+    P, hist = m.train(num_epochs=FULL_EPOCHS, learning_rate=0.1, print_each=None)
+    m.release()
+    assert sorted(hist) == sorted(r["hist"]) and all(len(hist[k]) == len(ref) for k, ref in r["hist"].items())     # (validation keys: empty lists)
+    for k, ref in r["hist"].items():
+        if len(ref):                           # (terms that are switched off are NaN in the reference's history, and in ours)
+            np.testing.assert_allclose(np.array([float(x) for x in hist[k]]), ref, rtol=0, equal_nan=True, err_msg=k,
+                                       atol=2 * pc.TOL["bf16x3"]["loss"] * max(1.0, float(np.nanmax(np.abs(ref))) if np.isfinite(ref).any() else 1.0))
+    assert len(r["hist"]["main_loss"]) == FULL_EPOCHS
+    rel = float(np.linalg.norm((P - r["P"]).astype(np.float64)) / np.linalg.norm(r["P"].astype(np.float64)))
+    assert P.dtype == r["P"].dtype and P.shape == r["P"].shape and rel <= FULL_BOUNDS["bf16x3"]["rel_P"], rel
+
+
 @pytest.mark.parametrize("name,prec", [("cfg2", "bf16x3"), ("cfg2", "fp32"), ("cfg2", "bf16"), ("cfg5a", "bf16x3"), ("cfg5b", "bf16x3")])
 def test_full_size_configurations_follow_the_unmodified_reference(ref_mo, name, prec):
     import json
