@@ -107,15 +107,20 @@ FULL_CASES = {"cfg2":  (False, dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5))
 _full_cache = {}
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _drop_full_size_references():
+    yield
+    _full_cache.clear()
+
+
 def _full_reference(ref_mo, name):
     """The reference `Mapper` / `MapperConstrained` as shipped at 30 000 x 1 000 x 10 000 (float32, torch CPU on the box's host
     cores, its own seeded logits; cfg5b: its dense 10 000 x 10 000 spot graphs), FULL_EPOCHS epochs: ~4 - 6 s per epoch at 32
-    threads.  One run per case, shared by the precisions; the previous case's arrays are dropped first (a case holds ~6 GB)."""
+    threads.  One run per case, shared by the tests below (a case holds ~6 GB of host arrays until the module is done)."""
     import torch
     from oracle import tangram_oracle as orc
     if name in _full_cache:
         return _full_cache[name]
-    _full_cache.clear()
     C, K, V = FULL_SHAPE
     constrained, lam = FULL_CASES[name]
     old = torch.get_num_threads()
@@ -230,3 +235,50 @@ def test_full_size_configurations_follow_the_unmodified_reference(ref_mo, name, 
     assert rec["frac_moved"] <= b["frac_moved"] and rec["rel_P"] <= b["rel_P"], rec
     if constrained:
         assert rec["max_dF"] <= b["F"], rec
+
+
+@pytest.mark.parametrize("name,world", [("cfg2", 8), ("cfg5a", 4)])
+def test_full_size_spot_shards_follow_the_unmodified_reference(ref_mo, name, world):
+    """BASELINE config 3's decomposition at full size: 30 000 x 1 000 x 10 000 as 8 spot shards of 1 250 (`tangram_amd.sharded`, the
+    sharded C step with its three exchanges; the shards are threads of this process on ONE GPU meeting in tests/local_comm.py, the
+    exchange sums in rank order) -- and the constrained class on 4 shards -- against the reference's single-process run: the same
+    bounds as the unsharded cases, and the global history bit-identical on every rank."""
+    import torch
+    from tangram_amd import _capi
+    from tangram_amd.sharded import make_sharded
+    from tests import parity_common as pc
+    from tests.local_comm import run_ranks
+    r = _full_reference(ref_mo, name)
+    data = r["data"]
+    constrained, lam = FULL_CASES[name]
+    kw = dict(F0=r["F0"], mode="constrained", target_count=r["target_count"]) if constrained else {}
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], r["M0"], d=data["d"], device="cuda:0", precision="bf16x3", lambdas=lam, comm=comm, **kw)
+        hist = sh.eng.new_history(FULL_EPOCHS)
+        sh.run(FULL_EPOCHS, 0.1, hist, 0)
+        res = sh.result_local(with_filter=constrained)
+        out = dict(hist=hist.cpu().numpy(), P=res[0].cpu().numpy(), range=res[1], F=res[2].cpu().numpy() if constrained else None,
+                   M=sh.eng.logits()[0][:, : sh.eng.V].cpu().numpy())
+        sh.release()
+        return out
+
+    res = run_ranks(world, rank_fn)
+    torch.cuda.synchronize()
+    assert [x["range"][0] for x in res] == sorted(x["range"][0] for x in res) and res[0]["range"][0] == 0 and res[-1]["range"][1] == FULL_SHAPE[2]
+    for x in res[1:]:
+        np.testing.assert_array_equal(x["hist"], res[0]["hist"])             # every rank holds the same global history
+    tol, b = pc.TOL["bf16x3"], FULL_BOUNDS["bf16x3"]
+    hh = res[0]["hist"].astype(np.float64)
+    if r["hist"] is not None:
+        assert np.abs(hh[:, _capi.H_MAIN] - r["hist"]["main_loss"]).max() <= 2 * tol["loss"]
+        assert np.abs(hh[:, _capi.H_TOTAL] - r["hist"]["total_loss"]).max() <= 2 * tol["loss"] * max(1.0, float(np.abs(r["hist"]["total_loss"]).max()))
+    dM = np.abs(np.concatenate([x["M"] for x in res], axis=1) - r["M"])
+    P = np.concatenate([x["P"] for x in res], axis=1)
+    rec = dict(max_dM=float(dM.max()), frac_moved=float((dM > 1e-3).mean()),
+               rel_P=float(np.linalg.norm((P - r["P"]).astype(np.float64)) / np.linalg.norm(r["P"].astype(np.float64))))
+    assert rec["frac_moved"] <= b["frac_moved"] and rec["rel_P"] <= b["rel_P"], rec
+    if constrained:
+        for x in res:
+            assert np.abs(x["F"] - r["F"]).max() <= b["F"]
+    print(name, world, rec)
