@@ -8,7 +8,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 export PYTHONUNBUFFERED=1
-(rocminfo | grep -E "Marketing|gfx" | head -4; nproc; lscpu | grep "Model name") > $O/env.log 2>&1
+(rocminfo | grep -E "Marketing|gfx" | head -4; nproc; lscpu | grep "Model name"; echo "cgroup memory.max: $(cat /sys/fs/cgroup/memory.max 2>/dev/null)"; free -g | head -2) > $O/env.log 2>&1
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 echo "== pytest gpu"; timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 echo "== bench default"; SECONDS=0; timeout 1200 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "rc=$? wall=${SECONDS}s"; tail -3 $O/bench_cfg2.err

@@ -113,6 +113,20 @@ def _drop_full_size_references():
     _full_cache.clear()
 
 
+def _host_memory_gb():
+    """Memory this process may use: the container's cgroup limit when there is one, else what the host reports as available."""
+    import psutil
+    avail = psutil.virtual_memory().available
+    for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(f).read().strip()
+            if v.isdigit():
+                avail = min(avail, int(v))
+        except OSError:
+            pass
+    return avail / 2 ** 30
+
+
 def _full_reference(ref_mo, name):
     """The reference `Mapper` / `MapperConstrained` as shipped at 30 000 x 1 000 x 10 000 (float32, torch CPU on the box's host
     cores, its own seeded logits; cfg5b: its dense 10 000 x 10 000 spot graphs), FULL_EPOCHS epochs: ~4 - 6 s per epoch at 32
@@ -121,6 +135,8 @@ def _full_reference(ref_mo, name):
     from oracle import tangram_oracle as orc
     if name in _full_cache:
         return _full_cache[name]
+    if _host_memory_gb() < 48:                 # the reference holds ~11 GB at this shape, the cached cases ~13 GB, the comparisons ~5 GB
+        pytest.skip("the full-size reference runs need ~48 GB of host memory")
     C, K, V = FULL_SHAPE
     constrained, lam = FULL_CASES[name]
     old = torch.get_num_threads()
