@@ -6,6 +6,8 @@ reference `Mapper` / `MapperConstrained` as shipped (float32, torch CPU, its own
 trains the library (real kernels, through the C ABI) from the same logits: loss trajectories, the mapping, the filter and the
 projection within the stated fp32 tolerances of tests/parity_common.py; plain bf16 within its own.
 Reference: tangram/mapping_optimizer.py:19-157 (construction), :189-309 (loss), :358-408 (train), :411-639 (constrained)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -331,8 +333,8 @@ def test_tutorial_clusters_shape_follows_the_unmodified_reference(ref_mo):
     ref_main = np.array([float(x) for x in hist["main_loss"]])
     ref_total = np.array([float(x) for x in hist["total_loss"]])
     e = HipMapperEngine(data["S"], data["G"], M0, d=d, d_source=ds, device="cuda:0", lambdas=lam)
-    geo = (__import__("ctypes").c_int * 8)()
-    assert e._lib.tg_debug_layout(__import__("ctypes").byref(e.cfg), geo) == 0 and geo[7] == 1, "this shape must run on the clusters-mode kernels"
+    geo = (ctypes.c_int * 8)()
+    assert e._lib.tg_debug_layout(ctypes.byref(e.cfg), geo) == 0 and geo[7] == 1, "this shape must run on the clusters-mode kernels"
     h = e.new_history(n)
     e.step(n, 0.1, h)
     torch.cuda.synchronize()
