@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counter passes (one rocprofv3 run per counter group, --pmc only: no trace domains) for bench.py.
-# usage: gpu_pmc.sh tag precision [traffic|all] [keep]   ("traffic": only the groups profiles/pmc_traffic.json is built from)
-TAG=${1:-pmc}; P=${2:-bf16x3}; MODE=${3:-all}; KEEP=${4:-}
+# usage: gpu_pmc.sh tag precision [traffic|all] [keep] ["extra bench args"]   ("traffic": only the groups profiles/pmc_traffic.json is built from)
+TAG=${1:-pmc}; P=${2:-bf16x3}; MODE=${3:-all}; KEEP=${4:-}; EXTRA=${5:-}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 [ -z "$KEEP" ] && rm -rf $R/gpurun_out/*
@@ -11,7 +11,7 @@ i=0
 while read -r GROUP; do
   i=$((i+1))
   if [ "$MODE" = traffic ]; then case "$GROUP" in SQ_VALU_MFMA*|TCC_HIT*|FETCH_SIZE|WRITE_SIZE|GRBM*) ;; *) continue;; esac; fi
-  timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d $O/g$i -o p -- python $R/bench.py --steps 3 --warmup 1 --precision $P --no-cpu-baseline --no-alt > $O/g$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $GROUP --output-format csv -d $O/g$i -o p -- python $R/bench.py --steps 3 --warmup 1 --precision $P --no-cpu-baseline --no-alt $EXTRA > $O/g$i.log 2>&1
   echo "group $i [$GROUP] rc=$?"
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES
@@ -43,7 +43,7 @@ for f in sorted(glob.glob(O+"/g*/**/*counter_collection.csv",recursive=True)):
             for c,v in agg[k].items():
                 line="%-44s %-28s avg_per_dispatch=%.6g n=%d"%(k,c,v/cnt[(k,c)],cnt[(k,c)])
                 o.write(line+"\n")
-                if "bwd" in k or "fwd" in k or "rowpass" in k: print(line)
+                if "bwd" in k or "fwd" in k or "rowpass" in k or "adam_update" in k: print(line)
     os.remove(f)
 PY
-find $O -size +512k -delete; du -sh $R/gpurun_out; tail -3 $O/g1.log
+find $O -size +512k -delete; du -sh $R/gpurun_out; tail -3 $O/g3.log
