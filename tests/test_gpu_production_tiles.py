@@ -9,6 +9,8 @@
 
 The checker is the oracle; the thing under test is the C-ABI library.  Tolerances: the stated fp32 tolerances of
 tests/parity_common.py (loss 1e-5, gradient rel 1e-5 vs fp64 / 1e-4 vs the fp32 torch run, whose own round-off is ~1e-6)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -338,3 +340,65 @@ def test_two_product_path_full_size_cfg2_first_steps_equal():
     assert res[1][2].startswith("bf16x3 (S exact")
     assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
     assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TG_FUZZ_SEEDS", "24"))))      # (TG_FUZZ_SEEDS=200: a wider one-off sweep)
+def test_random_production_geometries_against_oracle_fp64(seed):
+    """Seeded random problems LARGE enough for the production geometries -- 256^2 tiles, the 128 x 512 forward (padded gene counts
+    that are multiples of 512), several gene tiles, stream-K and forced piece counts of the forward, both backward tile sizes, the
+    two-product path on bf16-exact S -- with ragged cell / gene / spot counts, both mapper classes, 3 epochs against the fp64
+    oracle (the small random cases of tests/test_gpu_parity.py never leave the 128^2 geometry)."""
+    import torch
+    from oracle import tangram_oracle as orc
+    from tangram_amd import _capi
+    from tangram_amd.engine import HipMapperEngine
+    from tests import parity_common as pc
+    rng = np.random.default_rng(7000 + seed)
+    C = int(rng.integers(300, 5000))
+    K = int(rng.choice([int(rng.integers(1, 1600)), int(rng.integers(769, 1023)), int(rng.integers(1281, 1535)), 511, 1023]))
+    V = int(rng.integers(200, 3000))
+    prec = ["bf16x3", "bf16x3", "fp32", "bf16"][int(rng.integers(4))]
+    constrained = bool(rng.integers(3) == 0)
+    tile = int(rng.choice([0, 128, 256, 256]))
+    forced = int(rng.integers(3))
+    fwd_splits = 0 if forced == 0 else (int(rng.integers(1, 6)) if forced == 1 else -int(rng.integers(2, 300)))
+    bwd_tile = int(rng.choice([0, 0, 128, 256])) if tile != 128 else 0
+    s_exact = "auto" if (prec == "bf16x3" and rng.integers(2)) else False
+    data = orc.make_synthetic(C, K, V, seed=seed)
+    n = 3
+    pick = lambda vals: float(rng.choice(vals))
+    lam = dict(lambda_g1=1.0, lambda_d=pick([0.5, 1.0]), lambda_g2=pick([0.0, 0.5]), lambda_r=pick([0.0, 1e-3]))
+    kw = dict(device="cuda:0", precision=prec, tile_size=tile, fwd_splits=fwd_splits, bwd_tile=bwd_tile, s_exact=s_exact)
+    if constrained:
+        lam.update(lambda_count=1.0, lambda_f_reg=1.0)
+        tc = float(max(1, C // 3))
+        M0, F0 = orc.reference_init_MF_constrained(C, V, seed)
+        o = orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0, F0=F0, target_count=tc, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(n, 0.1)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], F0=F0, mode="constrained", lambdas=lam, target_count=tc, **kw)
+    else:
+        lam.update(lambda_l2=pick([0.0, 1e-5]))
+        M0 = orc.reference_init_M(C, V, seed)
+        o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(n, 0.1)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], lambdas=lam, **kw)
+    what = (seed, C, K, V, prec, constrained, tile, fwd_splits, bwd_tile, s_exact, e.effective_precision)
+    h = e.new_history(n)
+    e.step(n, 0.1, h)
+    torch.cuda.synchronize()
+    hh = h.cpu().numpy().astype(np.float64)
+    tol = pc.TOL[prec]
+    for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss")):
+        ref = np.array([float(x) for x in ho[k]])
+        assert np.abs(hh[:, col] - ref).max() <= 3 * tol["loss"] * max(1.0, np.abs(ref).max()), (what, k)
+    out = e.result(with_filter=constrained)
+    P = (out[0] if constrained else out).cpu().numpy()
+    assert np.abs(P - Po).max() <= tol["P"], what
+    rel = np.linalg.norm(P - Po) / np.linalg.norm(Po)
+    assert rel <= (1e-4 if prec != "bf16" else 2e-2), (what, rel)
+    if constrained:
+        assert np.abs(out[1].cpu().numpy() - Fo).max() <= (2e-5 if prec != "bf16" else 5e-3), what
+    Gh = e.project().cpu().numpy().astype(np.float64)
+    S_eff = data["S"].astype(np.float64) * (Fo[:, None] if constrained else 1.0)
+    ref = Po.T @ S_eff
+    assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= tol["ghat"], what
