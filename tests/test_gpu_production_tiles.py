@@ -402,3 +402,63 @@ def test_random_production_geometries_against_oracle_fp64(seed):
     S_eff = data["S"].astype(np.float64) * (Fo[:, None] if constrained else 1.0)
     ref = Po.T @ S_eff
     assert np.linalg.norm(Gh - ref) / np.linalg.norm(ref) <= tol["ghat"], what
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TG_FUZZ_SHARD_SEEDS", "10"))))
+def test_random_spot_shards_against_oracle_fp64(seed):
+    """The same kind of draw for the SHARDED step: 2 - 5 spot shards (threads of this process on one GPU, tests/local_comm.py) of a
+    random problem in the production geometries -- uneven shard widths, the row-dot backward on either tile size, both mapper
+    classes -- 3 epochs against the fp64 oracle of the unsharded problem; the global history bit-identical on every rank."""
+    from oracle import tangram_oracle as orc
+    from tangram_amd import _capi
+    from tangram_amd.sharded import make_sharded
+    from tests.local_comm import run_ranks
+    rng = np.random.default_rng(9000 + seed)
+    world = int(rng.integers(2, 6))
+    C = int(rng.integers(300, 4000))
+    K = int(rng.choice([int(rng.integers(1, 1300)), int(rng.integers(769, 1023)), 1000]))
+    V = int(rng.integers(world * 40, 2600))
+    prec = ["bf16x3", "bf16x3", "fp32", "bf16"][int(rng.integers(4))]
+    constrained = bool(rng.integers(3) == 0)
+    bwd_tile = int(rng.choice([0, 0, 128, 256]))
+    data = orc.make_synthetic(C, K, V, seed=100 + seed)
+    n = 3
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=float(rng.choice([0.0, 0.5])), lambda_r=float(rng.choice([0.0, 1e-3])))
+    kw = {}
+    if constrained:
+        lam.update(lambda_count=1.0, lambda_f_reg=1.0)
+        tc = float(max(1, C // 3))
+        M0, F0 = orc.reference_init_MF_constrained(C, V, seed)
+        o = orc.OracleMapperConstrained(data["S"], data["G"], data["d"], M0=M0, F0=F0, target_count=tc, dtype=np.float64, **lam)
+        Po, Fo, ho = o.train(n, 0.1)
+        kw = dict(F0=F0, mode="constrained", target_count=tc)
+    else:
+        M0 = orc.reference_init_M(C, V, seed)
+        o = orc.OracleMapper(data["S"], data["G"], d=data["d"], M0=M0, dtype=np.float64, **lam)
+        Po, ho = o.train(n, 0.1)
+    what = (seed, world, C, K, V, prec, constrained, bwd_tile)
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision=prec, lambdas=lam, comm=comm, bwd_tile=bwd_tile, **kw)
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist, 0)
+        res = sh.result_local(with_filter=constrained)
+        out = dict(hist=hist.cpu().numpy(), P=res[0].cpu().numpy(), range=res[1], F=res[2].cpu().numpy() if constrained else None)
+        sh.release()
+        return out
+
+    res = run_ranks(world, rank_fn)
+    for x in res[1:]:
+        np.testing.assert_array_equal(x["hist"], res[0]["hist"])
+    tol = pc.TOL[prec]
+    hh = res[0]["hist"].astype(np.float64)
+    for col, k in ((_capi.H_TOTAL, "total_loss"), (_capi.H_MAIN, "main_loss")):
+        ref = np.array([float(x) for x in ho[k]])
+        assert np.abs(hh[:, col] - ref).max() <= 3 * tol["loss"] * max(1.0, np.abs(ref).max()), (what, k)
+    assert res[0]["range"][0] == 0 and res[-1]["range"][1] == V
+    P = np.concatenate([x["P"] for x in res], axis=1)
+    assert np.abs(P - Po).max() <= tol["P"], what
+    assert np.linalg.norm(P - Po) / np.linalg.norm(Po) <= (1e-4 if prec != "bf16" else 2e-2), what
+    if constrained:
+        for x in res:
+            assert np.abs(x["F"] - Fo).max() <= (2e-5 if prec != "bf16" else 5e-3), what
