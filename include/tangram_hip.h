@@ -256,10 +256,10 @@ int tg_mapper_validate(tg_mapper* m, float* out4_dev);
 /* Checkpoint access (the reference's adata_map resume is a stub, mapping_optimizer.py:151-153):
  * raw pointers to M / Adam m / Adam v inside `state` and the step counter.                          */
 int tg_mapper_state(tg_mapper* m, float** M_dev, float** m1_dev, float** m2_dev, int32_t* pitch, int64_t* step);
-int tg_mapper_set_step(tg_mapper* m, int64_t step);
+int tg_mapper_set_step(tg_mapper* m, int64_t step);      /* after restoring state: recomputes the softmax statistics */
 /* The precision the handle computes in: a tg_precision value, or 3 = split bf16 with two matrix-core products per element (S was
  * found bf16-exact at create, tg_config.s_exact_mode); TG_PREC_F32 for clusters-mode handles (see tg_config.precision). */
-int tg_mapper_effective_precision(const tg_mapper* m);   /* after restoring state: recompute softmax statistics */
+int tg_mapper_effective_precision(const tg_mapper* m);
 /* Constrained mode: the filter logits F and their two Adam moments, three rows of `pitch` floats (row 0 = F, mapping_optimizer.py:
  * 486-493; rows 1, 2 = exp_avg, exp_avg_sq of torch.optim.Adam).  A checkpoint = these + tg_mapper_state; restore into a fresh
  * handle, then tg_mapper_set_step.  The resumed run equals the uninterrupted one up to the rounding of the softmax normaliser

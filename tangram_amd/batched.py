@@ -86,7 +86,8 @@ def _batch_key(m):
     if e.V > ROWPASS_MAX_SPOTS or e.K + 1 + 256 > EMIT_MAX_GENE_COLS or c.pipeline_bands > 1:
         return None
     stream = e._torch_stream.cuda_stream if e._torch_stream is not None else 0
-    return (type(m).__name__, e.C, e.K, e.V, e.precision, bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device), stream,
+    # (effective_precision: folds built with s_exact="auto" whose S differs in bf16-exactness run different GEMM kernels)
+    return (type(m).__name__, e.C, e.K, e.V, e.precision, getattr(e, "effective_precision", e.precision), bool(c.lambda_r or c.lambda_l1 or c.lambda_l2), str(e.device), stream,
             c.beta1, c.beta2, c.tile_size, c.fwd_splits)
 
 

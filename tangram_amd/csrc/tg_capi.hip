@@ -220,7 +220,17 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     // (measured, profiles/r02/run10_tiles: 30k x 1k x 500 and x 1000 are 8 - 11 % faster on 256 tiles, 20k x 1k x 324 is 14 % faster on
     //  128: there the spots pad to 512 instead of 384)
     const bool pad_ok = rup((size_t)L->V, 256) * 100 <= rup((size_t)L->V, 128) * 115;
-    L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 448 && pad_ok) ? 256 : 128);
+    // The tile copies (TgKtileDma, tg_kernels.h) address an operand tile through ONE buffer descriptor: byte count, per-lane offsets
+    // and the step offset are 32-bit, and out-of-range buffer loads are clamped to zero instead of faulting.  The longest operand rows
+    // are those of the forward's S^T image (one gene row = every cell: 4 bytes per cell in fp32 / split bf16, 2 in bf16): a tile of
+    // `rows` gene rows must stay below 4 GiB.  The geometry choice keeps it there (128 x 512 tiles up to ~2.1 M cells, 256^2 up to
+    // ~4.2 M, 128^2 up to ~8.4 M, twice that in bf16); beyond, create refuses instead of computing a wrong Ghat.
+    const size_t st_row_bytes = (rup((size_t)L->C, 64) / (size_t)L->BKE) * 128;
+    auto dma_fits = [&](int rows) { return (size_t)rows * st_row_bytes < ((size_t)1 << 32); };
+    L->T = cfg->tile_size ? cfg->tile_size : ((L->C >= 4096 && L->V >= 448 && pad_ok && dma_fits(256)) ? 256 : 128);
+    if (!dma_fits(L->T))
+        return tg_fail(TG_ERR_UNSUPPORTED, "n_cells = %d: a %d-row tile of the S^T operand image (%zu bytes per gene row) exceeds the 32-bit tile offsets of the copy engine path%s",
+                       L->C, L->T, st_row_bytes, cfg->tile_size == 256 ? " (tile_size 128 or 0 would fit)" : "");
     L->has_nb = cfg->lambda_neighborhood_g1 > 0.f;
     L->has_ct = cfg->lambda_ct_islands > 0.f;
     L->has_ac = cfg->lambda_getis_ord > 0.f || cfg->lambda_moran > 0.f || cfg->lambda_geary > 0.f;
@@ -247,7 +257,9 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     L->Cp = (int)rup(L->C, 64);
     L->Cr = (int)rup(L->C, L->T);
     L->nvt = L->Vr / L->T; L->nct = L->Cr / L->T; L->nkt = L->Kp / L->T;
-    L->fwd_wide = (TG_FWD_WIDE && L->T == 256 && L->Kp % 512 == 0 && cfg->precision == TG_PREC_BF16X3) ? 1 : 0;   // (measured: plain bf16 is faster on 256^2, profiles/r02/run8_wide)
+    if ((size_t)L->T * ((size_t)L->Kp / (size_t)L->BKE) * 128 >= ((size_t)1 << 32))      // backward operand tiles: rows of Kp genes
+        return tg_fail(TG_ERR_UNSUPPORTED, "n_genes = %d: an operand tile exceeds the 32-bit tile offsets of the copy engine path", L->K);
+    L->fwd_wide = (TG_FWD_WIDE && L->T == 256 && L->Kp % 512 == 0 && cfg->precision == TG_PREC_BF16X3 && dma_fits(512)) ? 1 : 0;   // (measured: plain bf16 is faster on 256^2, profiles/r02/run8_wide)
     // Tile edge of the backward GEMM.  Under the 256 layout both 256^2 (one workgroup per CU) and 128^2 (two) are legal; the choice
     // is a FIXED function of the shape (round 2 timed both on the first step: a hidden host synchronisation inside tg_mapper_step
     // and a box-dependent kernel choice).  With the dense XCD-banded tile map 256^2 wins or ties every X-only shape measured

@@ -56,6 +56,11 @@ TG_DEV float tg_log(float x) { return logf(x); }
 TG_DEV float tg_exp2(float x) { return exp2f(x); }
 #endif
 TG_DEV float tg_shfl_xor(float v, int mask) { return hipsim::shfl_idx(v, hipsim::lane_id() ^ mask); }
+TG_DEV float tg_bfly(float v, int mask) { return tg_shfl_xor(v, mask); }      // (see the HIP build below)
+// Adam's square root and its two divisions as IEEE evaluates them (the HIP build's cheap forms are correctly / faithfully rounded)
+TG_DEV float tg_sqrt_cr(float x) { return sqrtf(x); }
+TG_DEV float tg_div_by(float s, float b, float inv_b) { (void)inv_b; return s / b; }
+TG_DEV float tg_div_fr(float a, float b) { return a / b; }
 TG_DEV int tg_lane() { return hipsim::lane_id(); }
 TG_DEV int tg_uniform(int x) { return x; }
 TG_DEV unsigned tg_pack_bf16(float lo, float hi) {
@@ -107,6 +112,52 @@ TG_DEV float tg_exp(float x) { return __expf(x); }
 TG_DEV float tg_log(float x) { return __logf(x); }
 TG_DEV float tg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
 TG_DEV float tg_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// One step of a BUTTERFLY all-reduce over the wave (steps in the order 1, 2, 4, 8, 16, 32): the partner's value.  Masks 1 - 8 are DPP
+// modifiers of a v_mov (no LDS crossbar trip like ds_bpermute): quad_perm for 1 and 2; row_half_mirror (lane i <-> 7 - i = i ^ 7) for
+// 4 and row_mirror (i ^ 15) for 8 -- inside a butterfly the lanes of a quad / of an 8-group already agree when those steps run, so
+// the value read equals the one at lane ^ 4 / lane ^ 8 (the emulator reads exactly those: same bits).  16 and 32: ds_bpermute.
+TG_DEV float tg_bfly(float v, int mask) {
+    const int x = __builtin_bit_cast(int, v);
+    int y;
+    switch (mask) {
+        case 1: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;     // quad_perm [1, 0, 3, 2]
+        case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;     // quad_perm [2, 3, 0, 1]
+        case 4: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;    // row_half_mirror
+        case 8: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;    // row_mirror
+        default: return __shfl_xor(v, mask, 64);
+    }
+    return __builtin_bit_cast(float, y);
+}
+// ---- Adam's square root and divisions (torch _single_tensor_adam: denom = sqrt(v) / bias_correction2_sqrt + eps; m / denom) without
+// hipcc's IEEE sequences (sqrtf: denormal scaling + v_sqrt_f32 + two-sided ulp fix-up, ~19 issue slots; a division: v_div_scale x 2,
+// v_rcp_f32, four fma, v_div_fmas, v_div_fixup, ~13 slots -- 45 of the update kernel's 89 VALU slots per element in round 4).
+// tg_sqrt_cr: v_rsq_f32 + one coupled Goldschmidt / Newton step with fma residuals (the sequence LLVM's own lowering uses when it need
+// not keep denormals): correctly rounded for normal x.  Zero, denormal and infinite x are returned as they are: IEEE gives sqrt(x)
+// <= 1.1e-19 for a denormal x, which vanishes against eps in `sqrt(v) / bc + eps` for any eps >= 1e-11 (Adam's is 1e-8): the
+// denominator is the same float.
+TG_DEV float tg_sqrt_cr(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y, h = 0.5f * y;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    g = __builtin_fmaf(g, e, g);
+    const float d = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(d, h, g);
+    return __builtin_amdgcn_classf(x, 0x260 | 0x090) ? x : g;      // +-0 (0x060), +inf (0x200), +-denormal (0x090)
+}
+// s / b for a wave-uniform b whose correctly rounded reciprocal inv_b the host supplies: quotient estimate + one fma-residual
+// correction (Markstein): correctly rounded.
+TG_DEV float tg_div_by(float s, float b, float inv_b) {
+    const float q = s * inv_b;
+    return __builtin_fmaf(__builtin_fmaf(-q, b, s), inv_b, q);
+}
+// a / b, b normal and positive (Adam's denominator, >= eps): v_rcp_f32 (1 ulp) + one residual correction: faithfully rounded (the
+// IEEE quotient in all but a few 1e-3 of the cases, else its neighbour).
+TG_DEV float tg_div_fr(float a, float b) {
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float q = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-q, b, a), y, q);
+}
 TG_DEV int tg_lane() { return threadIdx.x & 63; }
 TG_DEV int tg_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 TG_DEV unsigned tg_pack_bf16(float lo, float hi) {        // -> v_cvt_pk_bf16_f32 (RNE)

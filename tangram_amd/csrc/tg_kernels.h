@@ -1739,6 +1739,81 @@ struct TgUpdateArgs {
     TgFinalizeArgs fin;                               //    (tg_loss_scalars; see tg_dghat_emit<SELF>)
 };
 
+// ---- the arithmetic of one element, shared by both update kernels -------------------------------------------------------------
+// Round 5 ("the update on a diet": round 4 counted 89 VALU instructions per element, SQ_INSTS_VALU): the softmax weight P of pass 1 is
+// kept for pass 2 instead of a second exponential; Adam's square root and two divisions are tg_sqrt_cr / tg_div_by / tg_div_fr
+// (tg_device.h) instead of hipcc's IEEE sequences; whole quads of a row run without per-element predication (only the one quad of a row
+// that straddles V takes the masked path); the new row's (max, sum exp) is taken as a per-thread maximum first and ONE pass of
+// exponentials against it, instead of an online rescale per quad; the wave reductions are DPP butterflies.
+struct TgAdamK { float b1c, beta2, b2c, bc2, ibc2, eps, step; };
+TG_DEV TgAdamK tg_adam_k(const TgUpdateArgs& a) {
+    TgAdamK k;
+    k.b1c = 1.f - a.beta1; k.beta2 = a.beta2; k.b2c = 1.f - a.beta2; k.bc2 = a.bc2_sqrt; k.ibc2 = 1.f / a.bc2_sqrt; k.eps = a.eps; k.step = a.step_size;
+    return k;
+}
+// exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/bc2 + eps; p.addcdiv_(m, denom, -step)
+TG_DEV void tg_adam_elem(float gm, float& mo, float& m1, float& m2, const TgAdamK& k) {
+    m1 = m1 + (gm - m1) * k.b1c;
+    m2 = m2 * k.beta2 + k.b2c * gm * gm;
+    const float den = tg_div_by(tg_sqrt_cr(m2), k.bc2, k.ibc2) + k.eps;
+    mo = mo - k.step * tg_div_fr(m1, den);
+}
+// the row-uniform constants of the softmax backward
+struct TgRowK { float sh, iz, fg, wc, logiz, lr, l1, l2; };
+// dP of one element (mapping_optimizer.py:202 backward + the density term + the entropy term)
+template <bool FULL> TG_DEV float tg_dp_elem(float x, float aq, float mo, const TgRowK& r) {
+    if constexpr (!FULL) return x + aq * r.wc;               // (the filter gate exists in constrained mode only, which is FULL)
+    else {
+        float dp = r.fg * (x + aq * r.wc);
+        if (r.lr != 0.f) dp -= r.lr * ((mo - r.sh) + r.logiz + 1.f);
+        return dp;
+    }
+}
+template <bool FULL> TG_DEV float tg_gm_elem(float p, float dp, float rc, float mo, const TgRowK& r) {
+    float gm = p * (dp - rc);
+    if constexpr (FULL) {
+        if (r.l1 != 0.f) gm += r.l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
+        if (r.l2 != 0.f) gm += 2.f * r.l2 * mo;
+    }
+    return gm;
+}
+// butterfly all-reduce over the wave (fixed order)
+TG_DEV float tg_wave_sum(float x) {
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) x += tg_bfly(x, m);
+    return x;
+}
+TG_DEV float tg_wave_max(float x) {
+#pragma unroll
+    for (int m = 1; m <= 32; m <<= 1) x = tg_fmax(x, tg_bfly(x, m));
+    return x;
+}
+// (max, sum exp) of the new row from the per-thread (max, sum exp against that max): the wave's maximum first, ONE rescale per thread,
+// a plain wave sum; then the waves through LDS in wave order.  Thread 0 writes the pair (and, single GPU, the forward's row constants).
+template <int NW>
+TG_DEV void tg_row_stats_out(float tmax, float tsum, float* red, const TgUpdateArgs& a, int c, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    const float wmax = tg_wave_max(tmax);
+    const float wsum = tg_wave_sum(tsum * tg_exp(tmax - wmax));        // (a thread without elements: 0 * exp(-big) = 0)
+    if (lane == 0) { red[wave * 2] = wmax; red[wave * 2 + 1] = wsum; }
+    __syncthreads();
+    if (t == 0) {
+        float mx = red[0];
+        for (int w = 1; w < NW; ++w) mx = tg_fmax(mx, red[w * 2]);
+        float z = 0.f;
+        for (int w = 0; w < NW; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
+        a.pair_out[c] = mx;
+        a.pair_out[a.C + c] = z;
+        if (a.finalize) {
+            const float inz = 1.f / z;
+            a.new_shift[c] = mx;
+            a.new_invz[c] = inz;
+            a.new_mul[c] = inz;                                // (the constrained filter is folded in by tg_merge_stats)
+            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
+        }
+    }
+}
+
 // NT = 256 threads per cell; 1 024 for a handful of long rows (clusters mode beyond 16 384 spots: with 18 workgroups the kernel is
 // one dependent chain of V / (4 NT) trips per thread -- 81 us at 50 000 spots with 256 threads)
 template <bool FULL, bool X16, bool STREAM, int NT = 256>
@@ -1747,12 +1822,17 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(NT) tg_adam_update(TgUpdateArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [NW waves][2]  (history workgroup: [NW][5])
     if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
-    const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float sh = a.rshift[c], iz = a.rinvz[c], rc = a.r[c];
-    const float fg = a.fgate ? a.fgate[c] : 1.f;
-    const float wc = a.dens_w ? a.dens_w[c] : 1.f;
-    const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
+    const int c = a.c_begin + blockIdx.x, t = threadIdx.x;
+    TgRowK rk;
+    rk.sh = a.rshift[c]; rk.iz = a.rinvz[c];
+    rk.fg = a.fgate ? a.fgate[c] : 1.f;
+    rk.wc = a.dens_w ? a.dens_w[c] : 1.f;
+    rk.lr = a.lambda_r; rk.l1 = a.lambda_l1; rk.l2 = a.lambda_l2;
+    rk.logiz = (FULL && a.lambda_r != 0.f) ? tg_log(rk.iz) : 0.f;
+    const float rc = a.r[c];
+    const TgAdamK ak = tg_adam_k(a);
     const size_t row = (size_t)c * a.Vp;
+    // (max, sum exp) of the new row, per thread: every trip rescales once against the trip's maximum (4 elements)
     float lmax = TG_NEG_BIG, lsum = 0.f;
     for (int v = 4 * t; v < a.V; v += 4 * NT) {
         f32x4 xq;
@@ -1767,25 +1847,27 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(NT) tg_adam_update(TgUpdateArgs a) {
         f32x4 m1 = tg_ld_stream<STREAM>((const f32x4*)(a.am + row + v));
         f32x4 m2 = tg_ld_stream<STREAM>((const f32x4*)(a.av + row + v));
         const f32x4 aq = *(const f32x4*)(a.vcoef + 2 * (size_t)a.Vr + v);
-        float nm[4];
         float qmax = TG_NEG_BIG;
+        if (v + 4 <= a.V) {                                    // a whole quad: no per-element predication
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = (v + e) < a.V;
-            const float mo = mq[e];
-            const float p = tg_exp(mo - sh) * iz;
-            float dp = fg * (xq[e] + aq[e] * wc);
-            if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + logiz + 1.f);
-            float gm = p * (dp - rc);
-            if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
-            if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
-            // exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/bc2 + eps; p.addcdiv_(m, denom, -step)
-            const float e1 = m1[e] + (gm - m1[e]) * (1.f - a.beta1);
-            const float e2 = m2[e] * a.beta2 + (1.f - a.beta2) * gm * gm;
-            const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
-            const float mn = mo - a.step_size * (e1 / den);
-            if (ok) { mq[e] = mn; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mn); }
-            nm[e] = ok ? mn : TG_NEG_BIG;
+            for (int e = 0; e < 4; ++e) {
+                float mo = mq[e], e1 = m1[e], e2 = m2[e];
+                const float p = tg_exp(mo - rk.sh) * rk.iz;
+                const float gm = tg_gm_elem<FULL>(p, tg_dp_elem<FULL>(xq[e], aq[e], mo, rk), rc, mo, rk);
+                tg_adam_elem(gm, mo, e1, e2, ak);
+                mq[e] = mo; m1[e] = e1; m2[e] = e2;
+                qmax = tg_fmax(qmax, mo);
+            }
+        } else {                                               // the quad that straddles V (at most one per row)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = (v + e) < a.V;
+                float mo = mq[e], e1 = m1[e], e2 = m2[e];
+                const float p = tg_exp(mo - rk.sh) * rk.iz;
+                const float gm = tg_gm_elem<FULL>(p, tg_dp_elem<FULL>(xq[e], aq[e], mo, rk), rc, mo, rk);
+                tg_adam_elem(gm, mo, e1, e2, ak);
+                if (ok) { mq[e] = mo; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mo); }
+            }
         }
         tg_st_stream<STREAM>(mq, (f32x4*)(a.M + row + v));
         tg_st_stream<STREAM>(m1, (f32x4*)(a.am + row + v));
@@ -1793,55 +1875,34 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(NT) tg_adam_update(TgUpdateArgs a) {
         const float nmx = tg_fmax(lmax, qmax);
         float qs = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qs += (nm[e] > TG_NEG_BIG) ? tg_exp(nm[e] - nmx) : 0.f;
+        for (int e = 0; e < 4; ++e) qs += ((v + e) < a.V) ? tg_exp(mq[e] - nmx) : 0.f;
         lsum = lsum * tg_exp(lmax - nmx) + qs;
         lmax = nmx;
     }
-    // (max, sum exp) of the whole new row: wave shuffle tree, then the waves through LDS (fixed order)
-#pragma unroll
-    for (int msk = 1; msk <= 32; msk <<= 1) {
-        const float om = tg_shfl_xor(lmax, msk), os = tg_shfl_xor(lsum, msk);
-        const float nmx = tg_fmax(lmax, om);
-        lsum = lsum * tg_exp(lmax - nmx) + os * tg_exp(om - nmx);
-        lmax = nmx;
-    }
-    if (lane == 0) { red[wave * 2] = lmax; red[wave * 2 + 1] = lsum; }
-    __syncthreads();
-    if (t == 0) {
-        float mx = red[0];
-        for (int w = 1; w < NW; ++w) mx = tg_fmax(mx, red[w * 2]);
-        float z = 0.f;
-        for (int w = 0; w < NW; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
-        a.pair_out[c] = mx;
-        a.pair_out[a.C + c] = z;
-        if (a.finalize) {
-            const float inz = 1.f / z;
-            a.new_shift[c] = mx;
-            a.new_invz[c] = inz;
-            a.new_mul[c] = 1.f / z;                            // (the constrained filter is folded in by tg_merge_stats)
-            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
-        }
-    }
+    tg_row_stats_out<NW>(lmax, lsum, red, a, c, t);
 }
 
 // K4': the same update for the single-GPU schedule, with the softmax-backward row dot taken in the SAME kernel:
 // one workgroup of NT threads per cell holds its whole row of M, X and both moments in registers (NQ float4 per thread
 // per array, V <= 4 * NT * NQ; every load of the row is in flight before the first use),
-//   pass 1: P, dP -> r_c (block reduction; plus the entropy / L1 / L2 / filter row sums when FULL),
-//   pass 2: dM = P (dP - r_c), Adam, stores, (max, sum exp) of the new row.
+//   pass 1: P, dP -> r_c (block reduction; plus the entropy / L1 / L2 / filter row sums when FULL); P stays in registers,
+//   pass 2: dM = P (dP - r_c), Adam, stores, then (max, sum exp) of the new row.
 // HBM traffic is that of tg_adam_update; tg_bwd_kernel no longer reads M nor writes row-dot partials.
 template <bool FULL, bool X16, int NQ, int NT, bool STREAM>
 TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
     TG_LDS_DECL;
-    float* red = (float*)tg_lds;          // [NW waves][TGP1_N] then [NW][2]
     constexpr int NW = NT / 64;
-    if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
     constexpr int NP = FULL ? (int)TGP1_N : 1;
+    float* red = (float*)tg_lds;          // [NW waves][NP] (pass 1), then [NW][2] behind it (row statistics): no reuse, one barrier each
+    float* red2 = red + NW * NP;
+    if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
     const int c = a.c_begin + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float sh = a.rshift[c], iz = a.rinvz[c];
-    const float fg = a.fgate ? a.fgate[c] : 1.f;
-    const float wc = a.dens_w ? a.dens_w[c] : 1.f;
-    const float logiz = (FULL && a.lambda_r != 0.f) ? tg_log(iz) : 0.f;
+    TgRowK rk;
+    rk.sh = a.rshift[c]; rk.iz = a.rinvz[c];
+    rk.fg = a.fgate ? a.fgate[c] : 1.f;
+    rk.wc = a.dens_w ? a.dens_w[c] : 1.f;
+    rk.lr = a.lambda_r; rk.l1 = a.lambda_l1; rk.l2 = a.lambda_l2;
+    rk.logiz = (FULL && a.lambda_r != 0.f) ? tg_log(rk.iz) : 0.f;
     const size_t row = (size_t)c * a.Vp;
     const float* avec = a.vcoef + 2 * (size_t)a.Vr;
     f32x4 mq[NQ];
@@ -1859,11 +1920,10 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
         if constexpr (X16) xr[q] = tg_ld_stream<STREAM>((const u32x2*)((const unsigned short*)a.X + row + vl));
         else xr[q] = tg_ld_stream<STREAM>((const f32x4*)((const float*)a.X + row + vl));
     }
-    // the moments travel while pass 1 computes -- except that the regularised variants at the 128-register limit (4 waves per SIMD,
-    // NT * NQ = 2560) request the second moment only behind the pass-1 sums, under the block reduction: all four arrays in flight
-    // at once left them 2 - 8 registers short (scratch spills in round 2)
-    constexpr bool LATE_M2 = FULL && STREAM && (NT * NQ == 2560);
-    f32x4 m1q[NQ], m2q[NQ];
+    // the moments travel while pass 1 computes -- except that the variants at the 128-register limit (4 waves per SIMD,
+    // NT * NQ = 2560) request the second moment only behind the pass-1 sums, under the block reduction
+    constexpr bool LATE_M2 = STREAM && (NT * NQ == 2560);
+    f32x4 m1q[NQ], m2q[NQ], pq[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int v = 4 * (t + NT * q);
@@ -1880,24 +1940,26 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
         if (v >= a.V) continue;
         const f32x4 aq = *(const f32x4*)(avec + v);
         const f32x4 xq = xval(q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if ((v + e) >= a.V) continue;
+        auto elem = [&](int e, bool ok) {                      // `ok` is the constant true on the whole-quad path: no selects there
             const float mo = mq[q][e];
-            const float p = tg_exp(mo - sh) * iz;
-            float dp = fg * (xq[e] + aq[e] * wc);
-            if (FULL) {
-                if (a.lambda_r != 0.f) {
-                    const float lp = (mo - sh) + logiz;
-                    dp -= a.lambda_r * (lp + 1.f);
-                    acc[TGP1_ENT % NP] += p * lp;
-                }
-                acc[TGP1_Q % NP] += p * xq[e];
-                acc[TGP1_PA % NP] += p * aq[e];
-                acc[TGP1_L1 % NP] += fabsf(mo);
-                acc[TGP1_L2 % NP] += mo * mo;
+            const float p = tg_exp(mo - rk.sh) * rk.iz;
+            pq[q][e] = p;
+            const float dp = tg_dp_elem<FULL>(xq[e], aq[e], mo, rk);
+            if constexpr (FULL) {
+                if (rk.lr != 0.f) acc[TGP1_ENT % NP] += ok ? p * ((mo - rk.sh) + rk.logiz) : 0.f;
+                acc[TGP1_Q % NP] += ok ? p * xq[e] : 0.f;
+                acc[TGP1_PA % NP] += ok ? p * aq[e] : 0.f;
+                acc[TGP1_L1 % NP] += ok ? fabsf(mo) : 0.f;
+                acc[TGP1_L2 % NP] += ok ? mo * mo : 0.f;
             }
-            acc[TGP1_R] += p * dp;
+            acc[TGP1_R] += ok ? p * dp : 0.f;
+        };
+        if (v + 4 <= a.V) {                                    // every quad but the one that straddles V
+#pragma unroll
+            for (int e = 0; e < 4; ++e) elem(e, true);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) elem(e, (v + e) < a.V);
         }
     }
     if constexpr (LATE_M2) {
@@ -1909,9 +1971,7 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        float x = acc[i];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) x += tg_shfl_xor(x, m);
+        const float x = tg_wave_sum(acc[i]);
         if (lane == 0) red[wave * NP + i] = x;
     }
     __syncthreads();
@@ -1924,69 +1984,55 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
         for (int w = 0; w < NW; ++w) x += red[w * NP + t];
         a.rowq_out[(size_t)t * a.C + c] = x;
     }
-    __syncthreads();                                   // `red` is reused below
     // ---- pass 2: Adam on the registers held since pass 1
-    float lmax = TG_NEG_BIG, lsum = 0.f;
+    const TgAdamK ak = tg_adam_k(a);
+    float tmax = TG_NEG_BIG;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int v = 4 * (t + NT * q);
         if (v >= a.V) continue;
-        f32x4 m1 = m1q[q], m2 = m2q[q];
+        f32x4 m1 = m1q[q], m2 = m2q[q], mo4 = mq[q];
         const f32x4 aq = *(const f32x4*)(avec + v);
         const f32x4 xq = xval(q);
-        f32x4 mo4 = mq[q];
-        float nm[4];
-        float qmax = TG_NEG_BIG;
+        if (v + 4 <= a.V) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = (v + e) < a.V;
-            const float mo = mo4[e];
-            const float p = tg_exp(mo - sh) * iz;
-            float dp = fg * (xq[e] + aq[e] * wc);
-            if (FULL && a.lambda_r != 0.f) dp -= a.lambda_r * ((mo - sh) + logiz + 1.f);
-            float gm = p * (dp - rc);
-            if (FULL && a.lambda_l1 != 0.f) gm += a.lambda_l1 * ((mo > 0.f) ? 1.f : ((mo < 0.f) ? -1.f : 0.f));
-            if (FULL && a.lambda_l2 != 0.f) gm += 2.f * a.lambda_l2 * mo;
-            const float e1 = m1[e] + (gm - m1[e]) * (1.f - a.beta1);
-            const float e2 = m2[e] * a.beta2 + (1.f - a.beta2) * gm * gm;
-            const float den = sqrtf(e2) / a.bc2_sqrt + a.eps;
-            const float mn = mo - a.step_size * (e1 / den);
-            if (ok) { mo4[e] = mn; m1[e] = e1; m2[e] = e2; qmax = tg_fmax(qmax, mn); }
-            nm[e] = ok ? mn : TG_NEG_BIG;
+            for (int e = 0; e < 4; ++e) {
+                float mo = mo4[e], e1 = m1[e], e2 = m2[e];
+                const float gm = tg_gm_elem<FULL>(pq[q][e], tg_dp_elem<FULL>(xq[e], aq[e], mo, rk), rc, mo, rk);
+                tg_adam_elem(gm, mo, e1, e2, ak);
+                mo4[e] = mo; m1[e] = e1; m2[e] = e2;
+                tmax = tg_fmax(tmax, mo);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = (v + e) < a.V;
+                float mo = mo4[e], e1 = m1[e], e2 = m2[e];
+                const float gm = tg_gm_elem<FULL>(pq[q][e], tg_dp_elem<FULL>(xq[e], aq[e], mo, rk), rc, mo, rk);
+                tg_adam_elem(gm, mo, e1, e2, ak);
+                if (ok) { mo4[e] = mo; m1[e] = e1; m2[e] = e2; tmax = tg_fmax(tmax, mo); }
+            }
         }
         tg_st_stream<STREAM>(mo4, (f32x4*)(a.M + row + v));
         tg_st_stream<STREAM>(m1, (f32x4*)(a.am + row + v));
         tg_st_stream<STREAM>(m2, (f32x4*)(a.av + row + v));
-        const float nmx = tg_fmax(lmax, qmax);
-        float qs = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) qs += (nm[e] > TG_NEG_BIG) ? tg_exp(nm[e] - nmx) : 0.f;
-        lsum = lsum * tg_exp(lmax - nmx) + qs;
-        lmax = nmx;
+        mq[q] = mo4;
     }
+    // ---- (max, sum exp) of the new row: the thread's maximum is known, one exponential per element against it
+    float tsum = 0.f;
 #pragma unroll
-    for (int msk = 1; msk <= 32; msk <<= 1) {
-        const float om = tg_shfl_xor(lmax, msk), os = tg_shfl_xor(lsum, msk);
-        const float nmx = tg_fmax(lmax, om);
-        lsum = lsum * tg_exp(lmax - nmx) + os * tg_exp(om - nmx);
-        lmax = nmx;
-    }
-    if (lane == 0) { red[wave * 2] = lmax; red[wave * 2 + 1] = lsum; }
-    __syncthreads();
-    if (t == 0) {
-        float mx = red[0];
-        for (int w = 1; w < NW; ++w) mx = tg_fmax(mx, red[w * 2]);
-        float z = 0.f;
-        for (int w = 0; w < NW; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
-        a.pair_out[c] = mx;
-        a.pair_out[a.C + c] = z;
-        if (a.finalize) {
-            a.new_shift[c] = mx;
-            a.new_invz[c] = 1.f / z;
-            a.new_mul[c] = 1.f / z;
-            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
+    for (int q = 0; q < NQ; ++q) {
+        const int v = 4 * (t + NT * q);
+        if (v >= a.V) continue;
+        if (v + 4 <= a.V) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tsum += tg_exp(mq[q][e] - tmax);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tsum += ((v + e) < a.V) ? tg_exp(mq[q][e] - tmax) : 0.f;
         }
     }
+    tg_row_stats_out<NW>(tmax, tsum, red2, a, c, t);
 }
 
 // ----------------------------------------------------------------------------------------------

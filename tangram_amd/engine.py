@@ -80,8 +80,8 @@ class HipMapperEngine:
         cfg.pipeline_bands = int(pipeline_bands)
         cfg.bwd_tile = int(bwd_tile)
         cfg.spot_offset = int(spot_offset)
-        if s_exact not in ("auto", True, False):
-            raise ValueError("s_exact must be False (the general three-product path, default) or 'auto' (check S once at construction)")
+        if s_exact is not False and s_exact != "auto":        # (True is refused: nobody may CLAIM exactness, the library checks it)
+            raise ValueError("s_exact must be False (always the general three-product path) or 'auto' (check S once at construction)")
         cfg.s_exact_mode = 0 if s_exact is False else 1
         for k, v in lam.items():
             setattr(cfg, k, float(v))
@@ -140,7 +140,8 @@ class HipMapperEngine:
         # library then also validates / projects such a handle in fp32 (tg_make_layout): `precision` is what was asked for,
         # `effective_precision` what runs.
         # `bf16x3` on a bf16-exact S (raw counts, one-hot columns): two matrix-core products per element instead of three, the
-        # same results (opt-in: `s_exact="auto"`; the default `s_exact=False` keeps the general path) -> "bf16x3 (S exact: 2 products)".
+        # same results (`s_exact="auto"`: the default of Mapper / MapperConstrained / map_cells_to_space; this low-level class
+        # defaults to the general path, `s_exact=False`) -> "bf16x3 (S exact: 2 products)".
         self.effective_precision = {0: "fp32", 1: "bf16", 2: "bf16x3", 3: "bf16x3 (S exact: 2 products)"}.get(
             int(self._lib.tg_mapper_effective_precision(self._h)), precision)
         self._scratch_row = torch.zeros(_capi.H_NTERMS, dtype=torch.float32, device=self.device)

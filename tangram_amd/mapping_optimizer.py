@@ -147,12 +147,14 @@ class Mapper:
         group=None,
         init="reference",
         gather_result=True,
-        s_exact=False,
+        s_exact="auto",
     ):
-        """Extra keywords (all opt-in; the defaults are the reference's behaviour):
-        s_exact="auto" (gemm_precision="bf16x3"): if every element of S is exactly representable in bf16 (raw counts below 256
-            are) both GEMMs run with two matrix-core products per element instead of three -- the same results, ~25 % less GEMM
-            time; otherwise (and by default) the general three-product path runs.
+        """Extra keywords (the defaults give the reference's results):
+        s_exact="auto" (default; only meaningful with gemm_precision="bf16x3"): the library checks S once at construction; if
+            every element is exactly representable in bf16 (raw counts below 256 are; normalised / log-transformed expression
+            is not) both GEMMs run with two matrix-core products per element instead of three -- the SAME values (the skipped
+            product adds exact zeros), ~25 % less GEMM time; otherwise the general three-product path runs.  `mapper.
+            _engine.effective_precision` says which one was taken.  s_exact=False: always the general path.
         init="device": the initial logits come from the library's counter-based device generator (device_init.py) instead of
             NumPy's global stream -- seed-reproducible (`random_state`), identical for every partition of the spots, and never
             materialised on the host: what a problem of BASELINE config 4's size needs (40 GB of logits; a sharded run with
@@ -326,7 +328,7 @@ class MapperConstrained:
         group=None,
         init="reference",
         gather_result=True,
-        s_exact=False,
+        s_exact="auto",
     ):
         """`init` / `gather_result` / `s_exact`: as for `Mapper` (init="device" also draws the filter logits F from the device generator)."""
         if adata_map is not None:

@@ -154,14 +154,15 @@ def map_cells_to_space(
     keep_mapper=False,
     distributed=False,
     group=None,
-    s_exact=False,
+    s_exact="auto",
     init="reference",
 ):
     """Map single cell data (`adata_sc`) on spatial data (`adata_sp`); see the reference docstring (:169-203).
 
-    Extra keywords: `s_exact="auto"`: two matrix-core products per element instead of three when the training-gene matrix of
-    `adata_sc` is bf16-exact (raw counts), same values; `init="device"`: initial logits from the library's device generator
-    instead of NumPy's stream (both opt-in, see tangram_amd.mapping_optimizer.Mapper); `gemm_precision` (tangram_amd.mapping_optimizer); `distributed=True` (+ optional `group`): shard the spots over
+    Extra keywords: `s_exact="auto"` (default): the library checks the training-gene matrix of `adata_sc` once; when it is bf16-exact
+    (raw counts) both GEMMs run two matrix-core products per element instead of three -- the same values --, otherwise (normalised /
+    log-transformed expression) the general three-product path; `s_exact=False` forces the general path; `init="device"` (opt-in):
+    initial logits from the library's device generator instead of NumPy's stream (see tangram_amd.mapping_optimizer.Mapper); `gemm_precision` (tangram_amd.mapping_optimizer); `distributed=True` (+ optional `group`): shard the spots over
     the ranks of an initialised torch.distributed process group -- opt-in, the same call on every rank, every rank gets the full
     result (tangram_amd.mapping_optimizer); `keep_mapper=True` leaves the trained mapper on the
     result as `adata_map._tangram_amd_mapper` so that `tangram_amd.project_genes(..., mapper=adata_map._tangram_amd_mapper)`

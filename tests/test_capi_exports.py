@@ -224,6 +224,40 @@ def test_launch_geometry_of_the_baseline_shapes():
     assert geo(2000, 100, 500, 2)[0] == 128
 
 
+def test_tile_copies_stay_inside_their_32_bit_offsets():
+    """The operand tiles are copied through one buffer descriptor per tile (TgKtileDma: 32-bit byte count and lane offsets; an
+    out-of-range buffer load returns zeros instead of faulting).  tg_make_layout must pick a forward geometry whose S^T tile --
+    rows x (4 bytes per cell) -- stays below 4 GiB, and refuse a pinned geometry that does not (round 4 advisor finding)."""
+    from tangram_amd import _build, _capi
+    lib = _capi._declare(ctypes.CDLL(_build.build()))
+    out = (ctypes.c_int * 8)()
+
+    def geo(C, K, V, prec, tile=0):
+        cfg = _capi.TgConfig()
+        cfg.abi_version = _capi.TG_ABI_VERSION
+        cfg.n_cells, cfg.n_genes, cfg.n_spots, cfg.tile_size = C, K, V, tile
+        cfg.lambda_g1, cfg.has_density, cfg.lambda_d, cfg.precision = 1.0, 1, 1.0, prec
+        rc = lib.tg_debug_layout(ctypes.byref(cfg), out)
+        return rc, list(out)
+
+    def tile_bytes(C, prec, rows):
+        cp = -(-C // 64) * 64
+        return rows * (cp // (64 if prec == 1 else 32)) * 128
+
+    rc, g = geo(2_000_000, 1000, 1000, 2)                 # just below the limit of the 128 x 512 forward tiles
+    assert rc == 0 and g[0] == 256 and g[5] == 1 and tile_bytes(2_000_000, 2, 512) < 2**32
+    rc, g = geo(2_200_000, 1000, 1000, 2)                 # 512 gene rows x 8.8 MB would wrap: 256^2 tiles instead
+    assert rc == 0 and g[0] == 256 and g[5] == 0 and tile_bytes(2_200_000, 2, 512) >= 2**32 > tile_bytes(2_200_000, 2, 256)
+    rc, g = geo(4_300_000, 1000, 1000, 2)                  # 256 rows wrap as well: 128^2
+    assert rc == 0 and g[0] == 128 and tile_bytes(4_300_000, 2, 256) >= 2**32 > tile_bytes(4_300_000, 2, 128)
+    rc, g = geo(4_300_000, 1000, 1000, 1)                  # plain bf16: 2 bytes per cell, 256^2 still fits
+    assert rc == 0 and g[0] == 256
+    rc, _ = geo(4_300_000, 1000, 1000, 2, tile=256)        # a pinned geometry that cannot address its tile is refused, with a message
+    assert rc == -4 and b"32-bit" in lib.tg_last_error()      # TG_ERR_UNSUPPORTED
+    rc, _ = geo(9_000_000, 1000, 1000, 2)                  # beyond every geometry
+    assert rc == -4
+
+
 def test_sizes_of_the_large_configurations_do_not_overflow():
     """tg_query_sizes on the host for BASELINE config 4 (200k x 2k x 50k, bf16: M + Adam moments = 120 GB on one GPU), its 1/8
     spot shard, and a problem far beyond any GPU: 64-bit byte counts, consistent with the documented layout."""

@@ -385,3 +385,74 @@ def test_full_size_properties_cfg4():
     del P_now, M, m1, m2, w
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def test_full_size_cfg4_as_eight_spot_shards():
+    """BASELINE config 4 in ITS decomposition -- 200 000 x 2 000 x 50 000, bf16 operands, the spots as 8 shards of 6 250 -- at full
+    size: the eight shards are threads of this process on ONE GPU (tests/local_comm.py; their exchanges sum in rank order) stepping
+    through the sharded C schedule from the seam's device-side initialiser (`make_sharded(..., device_init_seed=)`: every shard
+    generates exactly its columns of the 10^10-element plane, global offsets beyond 2^32).  Checked against the UNSHARDED run of the
+    same problem on the same GPU: the shards' logits are the unsharded run's columns (initially bit for bit, after the steps within
+    the bf16 bound of the full-size live-reference cases), and every rank holds the same global history, equal to the unsharded one."""
+    import gc
+    from tangram_amd.engine import HipMapperEngine
+    from tangram_amd.device_init import device_normal
+    from tangram_amd.sharded import make_sharded, shard_bounds
+    from tangram_amd.synthetic import make_workload
+    from tests.local_comm import run_ranks
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 250 * (1 << 30):
+        pytest.skip(f"needs ~230 GB of free HBM, {free >> 30} GB free")
+    C, K, V, world, n = 200000, 2000, 50000, 8, 4
+    lam = dict(lambda_g1=1.0, lambda_d=1.0)
+    w = make_workload(C, K, V, DEV, seed=0)
+    bounds = [shard_bounds(V, world, r) for r in range(world)]
+    cols = torch.tensor(sorted({c for lo, hi in bounds for c in (lo, lo + 1, (lo + hi) // 2, hi - 2, hi - 1)}), device=DEV)
+    # ---- the unsharded run: history + the sampled columns of the logits before and after
+    M0 = device_normal(C, V, DEV, seed=42)
+    e = HipMapperEngine(w["S"], w["G"], M0, d=w["d"], device=DEV, precision="bf16", lambdas=lam)
+    del M0
+    torch.cuda.empty_cache()
+    init_cols = e.logits()[0][:, cols].clone()
+    hist = e.new_history(n)
+    e.step(n, 0.1, hist)
+    ref_hist = hist.cpu().numpy().astype(np.float64)
+    ref_cols = e.logits()[0][:, cols].clone()
+    e.release()
+    del e, hist
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    # ---- the same problem as 8 spot shards
+    def rank_fn(comm):
+        sh = make_sharded(w["S"], w["G"], None, d=w["d"], device=DEV, precision="bf16", lambdas=lam, comm=comm, device_init_seed=42)
+        lo, hi = bounds[comm.rank]
+        mine = ((cols >= lo) & (cols < hi)).nonzero().flatten()
+        M = sh.eng.logits()[0]
+        assert M.shape[0] == C and sh.eng.V == hi - lo
+        first = M[:, cols[mine] - lo].clone()
+        h = sh.eng.new_history(n)
+        sh.run(n, 0.1, h, 0)
+        out = dict(hist=h.cpu().numpy(), idx=mine.cpu().numpy(), first=first, last=M[:, cols[mine] - lo].clone(), range=sh.result_local()[1])
+        sh.release()
+        return out
+
+    res = run_ranks(world, rank_fn)
+    torch.cuda.synchronize()
+    assert [x["range"] for x in res] == bounds and (C * V) > 2 ** 32
+    for x in res[1:]:
+        np.testing.assert_array_equal(x["hist"], res[0]["hist"])                 # the global history, identical on every rank
+    hh = res[0]["hist"].astype(np.float64)
+    live = [0, 1, 3]                                                             # total, gene score, KL
+    assert np.isfinite(hh[:, live]).all()
+    assert np.abs(hh[:, live] - ref_hist[:, live]).max() <= 1e-4 * max(1.0, np.abs(ref_hist[:, live]).max()), (hh[:, live], ref_hist[:, live])
+    for x in res:
+        idx = torch.as_tensor(x["idx"], device=DEV)
+        assert torch.equal(x["first"], init_cols[:, idx])                        # each shard generated exactly its columns
+        d = (x["last"] - ref_cols[:, idx]).abs()
+        assert float((d > 1e-3).float().mean()) <= 1e-4 and float(d.max()) < 1.0, (float(d.max()), float((d > 1e-3).float().mean()))
+    del res, w, init_cols, ref_cols
+    gc.collect()
+    torch.cuda.empty_cache()

@@ -353,3 +353,43 @@ def test_tutorial_clusters_shape_follows_the_unmodified_reference(ref_mo):
     # (every entry of a row of 9 852 probabilities is far below the absolute bound: the mapping is held relatively, and the logits
     #  themselves -- measured 2.0e-6 / 9.8e-5 after the 100 epochs, profiles/r04/run11_full_size_live)
     assert rec["max_dP"] <= tol["P"] and rec["rel_P"] <= 5e-5 and rec["max_dM"] <= 2e-3, rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# `s_exact="auto"` is the DEFAULT of the drop-in classes (round 5): which GEMM path an input takes, and that both are the reference's.
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["counts", "normalised"])
+def test_default_mapper_picks_the_gemm_path_from_the_data(ref_mo, kind):
+    """Raw counts (every element of S exactly a bf16 value) take the two-product split-bf16 path, a `normalize_total` + `log1p`
+    matrix (the tutorial's pre-processing: nothing exact about it) the general three-product path -- chosen by the library itself
+    at construction, `s_exact="auto"` being the default of `Mapper` -- and either way the run is the unmodified reference's from the
+    same seed within the fp32 bounds of the live-reference cases above."""
+    from tangram_amd.mapping_optimizer import Mapper
+    from oracle import tangram_oracle as orc
+    from tests import parity_common as pc
+    C, K, V, n = 2600, 300, 1300, 8
+    data = orc.make_synthetic(C, K, V, seed=21)
+    S = data["S"].astype(np.float32)
+    if kind == "normalised":
+        S = np.log1p(S / np.maximum(S.sum(1, keepdims=True), 1.0) * 1e4).astype(np.float32)     # sc.pp.normalize_total(target_sum=1e4); sc.pp.log1p
+        assert np.any(S != (S.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32))             # not bf16-exact
+    lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+    ref = ref_mo.Mapper(S=S, G=data["G"], d=data["d"], device="cpu", random_state=5, **lam)
+    P_ref, h_ref = ref.train(num_epochs=n, learning_rate=0.1, print_each=None)
+    m = Mapper(S=S, G=data["G"], d=data["d"], device="cuda:0", random_state=5, **lam)           # defaults: bf16x3, s_exact="auto"
+    want = "bf16x3 (S exact: 2 products)" if kind == "counts" else "bf16x3"
+    assert m._engine.effective_precision == want, (kind, m._engine.effective_precision)
+    P, h = m.train(num_epochs=n, learning_rate=0.1, print_each=None)
+    tol = pc.TOL["bf16x3"]
+    for k in ("total_loss", "main_loss", "vg_reg", "kl_reg"):
+        a, b = np.array([float(x) for x in h[k]]), np.array([float(x) for x in h_ref[k]])
+        assert np.abs(a - b).max() <= 2 * tol["loss"] * max(1.0, np.abs(b).max()), (kind, k)
+    assert np.abs(P - P_ref).max() <= tol["P"]
+    proj, proj_ref = P.astype(np.float64).T @ S.astype(np.float64), P_ref.astype(np.float64).T @ S.astype(np.float64)
+    assert np.linalg.norm(proj - proj_ref) / np.linalg.norm(proj_ref) <= tol["ghat"]
+    # and the forced general path gives the SAME values as the automatic two-product choice on count data
+    if kind == "counts":
+        m3 = Mapper(S=S, G=data["G"], d=data["d"], device="cuda:0", random_state=5, s_exact=False, **lam)
+        assert m3._engine.effective_precision == "bf16x3"
+        P3, _ = m3.train(num_epochs=n, learning_rate=0.1, print_each=None)
+        assert np.array_equal(P3, P)
