@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
 
 typedef enum tg_status {
     TG_OK = 0,
@@ -134,8 +134,9 @@ enum { TG_H_TOTAL = 0, TG_H_MAIN = 1, TG_H_VG = 2, TG_H_KL = 3, TG_H_ENTROPY = 4
  *   per-gene cosine statistics [2][Kp]            all-reduce(sum)   after the forward GEMM
  *   per-cell softmax-backward row dots [1|6][C]   all-reduce(sum)   after the backward GEMM
  *   per-cell (max, sum exp) of the new logits     all-gather        after the Adam update   (+ 2 history scalars per rank)
- * A tg_comm is either RCCL (librccl.so is dlopen'ed: collectives run on the handle's stream, no host code between the phases of a
- * step) or a pair of callbacks (any other transport: torch.distributed/gloo in the CPU tests, in-process shards in the GPU tests). */
+ * A tg_comm is RCCL (librccl.so is dlopen'ed: collectives run on the handle's stream, no host code between the phases of a
+ * step), a pair of callbacks (any other transport: torch.distributed/gloo in the CPU tests, in-process shards in the GPU tests), or
+ * peer memory (below: one-hop exchange kernels over mailboxes the ranks map from each other). */
 typedef struct tg_comm tg_comm;
 typedef int (*tg_all_reduce_sum_fn)(void* ctx, float* buf_dev, size_t n_floats, void* hip_stream);          /* in place; 0 = ok */
 typedef int (*tg_all_gather_fn)(void* ctx, const float* send_dev, float* recv_dev, size_t n_floats_per_rank, void* hip_stream);
@@ -146,6 +147,21 @@ int tg_comm_create_callbacks(int world, int rank, tg_all_reduce_sum_fn all_reduc
  * (the one PyTorch-ROCm ships is the natural choice); NULL = "librccl.so" by the loader's search path.                        */
 int tg_comm_rccl_unique_id(const char* librccl_path, void* id128_out);
 int tg_comm_create_rccl(const char* librccl_path, const void* id128, int world, int rank, tg_comm** out);
+/* Peer memory (ABI version 5): the third transport.  Every rank owns a MAILBOX in its own HBM which every peer maps (hipIpc between the
+ * processes of one node: xGMI stores; plain pointers between shards that live in one process); an exchange is ONE kernel per rank on
+ * the handle's stream and ONE hop: push this rank's vector into every mailbox, raise a flag, wait for the peers' flags in the own
+ * mailbox, sum in RANK ORDER (bit-identical on every rank) or copy out.  No collective library, no host code, no extra stream; its
+ * latency is a kernel launch plus one xGMI write, not a ring of 2 (N - 1) hops.  tg_comm_peer_create allocates the mailbox (fine-
+ * grained device memory: the one allocation this library makes, owned by the communicator) and returns a 64-byte handle; gather the
+ * handles of all ranks over any out-of-band channel (torch.distributed) and pass them, in rank order, to tg_comm_peer_connect.
+ * capacity_floats: the longest vector moved in one piece (longer ones go in pieces); same_process != 0: the handle is a raw device
+ * pointer (ranks are threads of one process on one GPU -- tests; give every rank its own stream: a rank's kernel waits for its peers'
+ * kernels).  One handle per peer communicator; sharded steps through it cannot be captured into a HIP graph (the sequence number of
+ * an exchange is a launch argument).  A poll that does not meet its peers within TG_PEER_TIMEOUT_MS (environment, default 20 000)
+ * gives up and sets a flag that tg_comm_peer_status reports: a lost peer costs a bounded wait, never a hang. */
+int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out);
+int tg_comm_peer_connect(tg_comm* c, const void* handles_world_x_64);
+int tg_comm_peer_status(tg_comm* c, int* timed_out);
 void tg_comm_destroy(tg_comm* c);
 
 int tg_abi_version(void);

@@ -21,13 +21,16 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     out = {}
-    for (C, K, V, parts, prec) in ((30000, 1000, 10000, 8, "bf16x3"), (30000, 1000, 10000, 4, "bf16x3"),
-                                   (30000, 1000, 10000, 2, "bf16x3"), (30000, 1000, 10000, 8, "bf16")):
+    # (transport "peer": the library's own one-hop exchange kernels; on ONE rank they push to and read from the rank's own mailbox,
+    #  i.e. the kernel's fixed cost without a link -- as the 1-rank RCCL collectives show RCCL's enqueue + local copy)
+    for (C, K, V, parts, prec, transport) in ((30000, 1000, 10000, 8, "bf16x3", "rccl"), (30000, 1000, 10000, 8, "bf16x3", "peer"),
+                                              (30000, 1000, 10000, 4, "bf16x3", "rccl"), (30000, 1000, 10000, 2, "bf16x3", "rccl"),
+                                              (30000, 1000, 10000, 8, "bf16", "rccl"), (30000, 1000, 10000, 8, "bf16", "peer")):
         Vl = V // parts
         w = make_workload(C, K, V, dev, seed=0)
         M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous()
         e = ShardedMapperEngine(w["S"], w["G"][:Vl].contiguous(), M0, w["d"][:Vl].contiguous(), n_spots_total=V,
-                                device=dev, precision=prec, lambdas=dict(lambda_g1=1.0, lambda_d=1.0))
+                                device=dev, precision=prec, lambdas=dict(lambda_g1=1.0, lambda_d=1.0), transport=transport)
         n = 100
         hist = e.eng.new_history(n)
         e.run(10, 0.1)
@@ -42,7 +45,8 @@ def main():
         torch.cuda.synchronize()
         kern = {name: round(1e3 * ms / max(cnt, 1), 1) for name, ms, cnt in e.eng.profile_read()}
         e.eng.profile(False)
-        out[f"{C}x{K}x{Vl}_of_{parts}_{prec}"] = dict(ms_per_step=1e3 * t_all / n, host_enqueue_ms_per_step=1e3 * t_enq / n,
+        e.peer_check()
+        out[f"{C}x{K}x{Vl}_of_{parts}_{prec}_{transport}"] = dict(ms_per_step=1e3 * t_all / n, host_enqueue_ms_per_step=1e3 * t_enq / n,
                                                       main_loss=float(hist[-1, 1]), kernels_us=kern)
         del e, w, M0
     print(json.dumps(out))

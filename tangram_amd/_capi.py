@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtangram_hip.so")      # the in-tree build, nothing else (experiments: scripts/with_lib.py)
 
-TG_ABI_VERSION = 4
+TG_ABI_VERSION = 5
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 H_NTERMS = 16
@@ -65,6 +65,11 @@ def _declare(lib):
     lib.tg_comm_create_callbacks.argtypes = [i32, i32, ALL_REDUCE_FN, ALL_GATHER_FN, vp, ct.POINTER(vp)]
     lib.tg_comm_rccl_unique_id.argtypes = [ct.c_char_p, vp]
     lib.tg_comm_create_rccl.argtypes = [ct.c_char_p, vp, i32, i32, ct.POINTER(vp)]
+    lib.tg_comm_peer_create.argtypes = [i32, i32, ct.c_size_t, i32, vp, ct.POINTER(vp)]
+    lib.tg_comm_peer_connect.argtypes = [vp, vp]
+    lib.tg_comm_peer_status.argtypes = [vp, ct.POINTER(i32)]
+    for name in ("tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status"):
+        getattr(lib, name).restype = i32
     lib.tg_comm_destroy.argtypes = [vp]
     lib.tg_comm_destroy.restype = None
     lib.tg_mapper_attach_comm.argtypes = [vp, vp]
@@ -106,7 +111,7 @@ def _declare(lib):
 
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
-           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_destroy",
+           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_destroy",
            "tg_mapper_attach_comm", "tg_mapper_result",
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
            "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step",

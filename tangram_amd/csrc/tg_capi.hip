@@ -1507,6 +1507,11 @@ struct tg_comm {
     int (*p_allgather)(const void*, void*, size_t, int, void*, void*);
     int (*p_destroy)(void*);
     const char* (*p_errstr)(int);
+    // peer-memory transport (tg_peer_exchange, tg_kernels.h): this rank's mailbox, every rank's mailbox as mapped here
+    unsigned char* box; unsigned char* peer[TG_PEER_MAX];
+    size_t cap, box_bytes; int nchunk_cap; unsigned seq; int peer_mode, connected;   // peer_mode 0: off; 1: hipIpc handles; 2: raw pointers
+    unsigned long long timeout_ticks;
+    char shm_name[64];                                                               // (emulated build: the mailbox is a POSIX shm object)
 };
 struct tg_nccl_id { char internal[128]; };     // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
 enum { TG_NCCL_FLOAT = 7, TG_NCCL_SUM = 0 };   // ncclFloat32, ncclSum (rccl.h)
@@ -1517,6 +1522,110 @@ extern "C" int tg_comm_create_callbacks(int world, int rank, tg_all_reduce_sum_f
     if (!c) return tg_fail(TG_ERR_INVALID, "out of host memory");
     c->world = world; c->rank = rank; c->ar = ar; c->ag = ag; c->ctx = ctx; c->lib = nullptr; c->nccl = nullptr;
     *out = c;
+    return TG_OK;
+}
+
+// ---- peer-memory transport ---------------------------------------------------------------------------------------------------
+#ifdef TG_SIM
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#endif
+static unsigned long long tg_peer_timeout_ticks() {
+    const char* e = getenv("TG_PEER_TIMEOUT_MS");
+    const double ms = (e && *e) ? atof(e) : 20000.0;
+    return (unsigned long long)((ms > 1.0 ? ms : 1.0) * 1e5);          // 10-ns ticks
+}
+extern "C" int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out) {
+    if (!out || !handle64_out || world < 1 || world > TG_PEER_MAX || rank < 0 || rank >= world || capacity_floats < 1)
+        return tg_fail(TG_ERR_INVALID, "bad peer communicator arguments (1 <= world <= %d)", TG_PEER_MAX);
+    tg_comm* c = new (std::nothrow) tg_comm();
+    if (!c) return tg_fail(TG_ERR_INVALID, "out of host memory");
+    memset(c, 0, sizeof *c);
+    c->world = world; c->rank = rank;
+    c->cap = rup(capacity_floats, TG_PEER_CHUNK);
+    c->nchunk_cap = (int)(c->cap / TG_PEER_CHUNK);
+    c->box_bytes = tg_peer_box_bytes(world, c->cap);
+    c->peer_mode = same_process ? 2 : 1;
+    c->timeout_ticks = tg_peer_timeout_ticks();
+    memset(handle64_out, 0, 64);
+#ifdef TG_SIM
+    if (same_process) {
+        c->box = (unsigned char*)calloc(1, c->box_bytes);
+        if (!c->box) { delete c; return tg_fail(TG_ERR_INVALID, "out of host memory"); }
+    } else {
+        static int counter = 0;
+        snprintf(c->shm_name, sizeof c->shm_name, "/tg_peer_%d_%d", (int)getpid(), counter++);
+        const int fd = shm_open(c->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)c->box_bytes) != 0) { if (fd >= 0) close(fd); delete c; return tg_fail(TG_ERR_HIP, "shm_open / ftruncate failed for the emulated mailbox"); }
+        c->box = (unsigned char*)mmap(nullptr, c->box_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (c->box == (unsigned char*)MAP_FAILED) { shm_unlink(c->shm_name); delete c; return tg_fail(TG_ERR_HIP, "mmap of the emulated mailbox failed"); }
+        memset(c->box, 0, c->box_bytes);
+        memcpy(handle64_out, c->shm_name, strlen(c->shm_name) + 1);
+    }
+#else
+    // fine-grained device memory: peers write it and this GPU reads it while kernels are running (coarse-grained allocations are
+    // only coherent at kernel boundaries).  The ONE device allocation of the library; it belongs to the communicator, not to a handle.
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, c->box_bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, c->box_bytes); }
+    if (e != hipSuccess) { delete c; return tg_fail(TG_ERR_HIP, "cannot allocate the %zu-byte mailbox (%s)", c->box_bytes, hipGetErrorString(e)); }
+    c->box = (unsigned char*)p;
+    if ((e = hipMemset(p, 0, c->box_bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        (void)hipFree(p); delete c; return tg_fail(TG_ERR_HIP, "clearing the mailbox failed (%s)", hipGetErrorString(e));
+    }
+    if (!same_process) {
+        hipIpcMemHandle_t h;
+        static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes the ABI reserves");
+        if ((e = hipIpcGetMemHandle(&h, p)) != hipSuccess) { (void)hipFree(p); delete c; return tg_fail(TG_ERR_HIP, "hipIpcGetMemHandle failed (%s)", hipGetErrorString(e)); }
+        memcpy(handle64_out, &h, sizeof h);
+    }
+#endif
+    if (same_process) memcpy(handle64_out, &c->box, sizeof c->box);
+    *out = c;
+    return TG_OK;
+}
+// handles: world x 64 bytes, rank r's from tg_comm_peer_create (gathered over any out-of-band channel).  Collective in the sense that
+// every rank must have created its mailbox before anybody connects.
+extern "C" int tg_comm_peer_connect(tg_comm* c, const void* handles) {
+    if (!c || !handles || !c->peer_mode) return tg_fail(TG_ERR_INVALID, "not a peer communicator");
+    if (c->connected) return tg_fail(TG_ERR_STATE, "peer communicator already connected");
+    for (int r = 0; r < c->world; ++r) {
+        const unsigned char* h = (const unsigned char*)handles + 64 * (size_t)r;
+        if (r == c->rank) { c->peer[r] = c->box; continue; }
+        if (c->peer_mode == 2) { memcpy(&c->peer[r], h, sizeof c->peer[r]); continue; }
+#ifdef TG_SIM
+        char name[64]; memcpy(name, h, 64); name[63] = 0;
+        const int fd = shm_open(name, O_RDWR, 0600);
+        if (fd < 0) return tg_fail(TG_ERR_HIP, "cannot open the emulated mailbox %s of rank %d", name, r);
+        void* p = mmap(nullptr, c->box_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return tg_fail(TG_ERR_HIP, "mmap of rank %d's emulated mailbox failed", r);
+        c->peer[r] = (unsigned char*)p;
+#else
+        hipIpcMemHandle_t ih; memcpy(&ih, h, sizeof ih);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return tg_fail(TG_ERR_HIP, "hipIpcOpenMemHandle for rank %d's mailbox failed (%s)", r, hipGetErrorString(e));
+        c->peer[r] = (unsigned char*)p;
+#endif
+    }
+    c->connected = 1;
+    return TG_OK;
+}
+// 0: every poll of every exchange so far met its peers; 1: a poll timed out (results since then are garbage).  Synchronises the device.
+extern "C" int tg_comm_peer_status(tg_comm* c, int* timed_out) {
+    if (!c || !timed_out || !c->peer_mode) return tg_fail(TG_ERR_INVALID, "not a peer communicator");
+    unsigned w = 0;
+#ifdef TG_SIM
+    w = *(volatile unsigned*)c->box;
+#else
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(&w, c->box, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return tg_fail(TG_ERR_HIP, "reading the mailbox status failed (%s)", hipGetErrorString(e));
+#endif
+    *timed_out = w ? 1 : 0;
     return TG_OK;
 }
 
@@ -1576,14 +1685,43 @@ extern "C" void tg_comm_destroy(tg_comm* c) {
     if (!c) return;
 #ifndef TG_SIM
     if (c->nccl && c->p_destroy) (void)c->p_destroy(c->nccl);
+    if (c->peer_mode) {
+        if (c->peer_mode == 1 && c->connected)
+            for (int r = 0; r < c->world; ++r) if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+        if (c->box) (void)hipFree(c->box);
+    }
+#else
+    if (c->peer_mode == 2) free(c->box);
+    else if (c->peer_mode == 1) {
+        if (c->connected) for (int r = 0; r < c->world; ++r) if (r != c->rank && c->peer[r]) munmap(c->peer[r], c->box_bytes);
+        if (c->box) { munmap(c->box, c->box_bytes); shm_unlink(c->shm_name); }
+    }
 #endif
     delete c;
+}
+
+// one exchange of the peer transport: pieces of at most `cap` floats, one kernel each (tg_peer_exchange)
+static int tg_peer_exchange_go(tg_mapper* m, const float* send, float* recv, size_t n, int gather) {
+    tg_comm* c = m->comm;
+    if (!c->connected) return tg_fail(TG_ERR_STATE, "peer communicator not connected (tg_comm_peer_connect)");
+    for (size_t off = 0; off < n; off += c->cap) {
+        const size_t piece = (n - off < c->cap) ? n - off : c->cap;
+        TgPeerArgs a;
+        for (int r = 0; r < TG_PEER_MAX; ++r) a.box[r] = r < c->world ? c->peer[r] : nullptr;
+        a.world = c->world; a.rank = c->rank; a.cap = c->cap; a.nchunk_cap = c->nchunk_cap;
+        c->seq += 1;
+        a.seq = c->seq; a.slot = (int)(c->seq & 1u);
+        a.send = send + off; a.recv = recv + off; a.n = piece; a.gather = gather; a.ld = n; a.timeout_ticks = c->timeout_ticks;
+        TG_LAUNCH(tg_peer_exchange, (piece + TG_PEER_CHUNK - 1) / TG_PEER_CHUNK, 1, 256, 0, m->stream, a);
+    }
+    return tg_launch_failed() ? tg_launch_status() : TG_OK;
 }
 
 static int tg_comm_all_reduce(tg_mapper* m, float* buf, size_t n) {
     tg_comm* c = m->comm;
     int e;
-    if (c->nccl) e = c->p_allreduce(buf, buf, n, TG_NCCL_FLOAT, TG_NCCL_SUM, c->nccl, (void*)m->stream);
+    if (c->peer_mode) { const int rc = tg_peer_exchange_go(m, buf, buf, n, 0); if (rc) return rc; e = 0; }
+    else if (c->nccl) e = c->p_allreduce(buf, buf, n, TG_NCCL_FLOAT, TG_NCCL_SUM, c->nccl, (void*)m->stream);
     else e = c->ar(c->ctx, buf, n, (void*)m->stream);
     if (e) return tg_fail(TG_ERR_HIP, "all-reduce of %zu floats failed with %d", n, e);
     tg_prof_mark(m, "exchange_all_reduce");
@@ -1592,7 +1730,8 @@ static int tg_comm_all_reduce(tg_mapper* m, float* buf, size_t n) {
 static int tg_comm_all_gather(tg_mapper* m, const float* send, float* recv, size_t n) {
     tg_comm* c = m->comm;
     int e;
-    if (c->nccl) e = c->p_allgather(send, recv, n, TG_NCCL_FLOAT, c->nccl, (void*)m->stream);
+    if (c->peer_mode) { const int rc = tg_peer_exchange_go(m, send, recv, n, 1); if (rc) return rc; e = 0; }
+    else if (c->nccl) e = c->p_allgather(send, recv, n, TG_NCCL_FLOAT, c->nccl, (void*)m->stream);
     else e = c->ag(c->ctx, send, recv, n, (void*)m->stream);
     if (e) return tg_fail(TG_ERR_HIP, "all-gather of %zu floats per rank failed with %d", n, e);
     tg_prof_mark(m, "exchange_all_gather");

@@ -12,6 +12,9 @@ exchanges -- is issued by the C library inside `tg_mapper_step` (include/tangram
   * transport "rccl": the library binds librccl.so itself and calls ncclAllReduce / ncclAllGather on the handle's stream, between
     its own kernels: no Python, no second stream and no event between a kernel and the collective that consumes its output.
     The communicator is bootstrapped with one 128-byte broadcast over torch.distributed.
+  * transport "peer" (round 5, opt-in: `transport="peer"` or TG_SHARD_TRANSPORT=peer): no collective library at all -- every rank owns a
+    mailbox in its HBM that its peers map (hipIpc), an exchange is ONE kernel on the handle's stream and ONE xGMI hop (push to every
+    mailbox, flag, wait for the peers' flags, sum in rank order): the latency of a kernel launch, not of a 2 (N - 1)-hop ring.
   * transport "callbacks": the library calls back into this module, which runs the collective through any object with
     `all_reduce(t)` / `all_gather_into_tensor(out, t)` (torch.distributed with gloo in the CPU tests, an in-process communicator
     for several shards of one GPU in the GPU tests).
@@ -29,6 +32,14 @@ import torch.distributed as dist
 
 from . import _capi
 from .engine import HipMapperEngine
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class DistComm:
@@ -50,6 +61,9 @@ class DistComm:
 
     def broadcast(self, t, src=0):
         dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+
+    def barrier(self):
+        dist.barrier(group=self.group)
 
 
 def shard_bounds(n, world, rank, blocks=False):
@@ -103,6 +117,8 @@ class ShardedMapperEngine:
         self.n_spots_total = int(n_spots_total)
         lib = self.eng._lib
         if transport == "auto":
+            transport = os.environ.get("TG_SHARD_TRANSPORT", "auto")      # (bench / experiments: "peer", "rccl", "callbacks")
+        if transport == "auto":
             is_nccl = comm is None and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
             transport = "rccl" if (is_nccl and not _capi.is_emulated() and self.eng.device.type == "cuda") else "callbacks"
         self.transport = transport
@@ -125,10 +141,38 @@ class ShardedMapperEngine:
             self._cb_ar = _capi.ALL_REDUCE_FN(self._cb_all_reduce)       # (kept alive: the C side stores the function pointers)
             self._cb_ag = _capi.ALL_GATHER_FN(self._cb_all_gather)
             _capi.check(lib.tg_comm_create_callbacks(self.world, self.rank, self._cb_ar, self._cb_ag, None, ct.byref(handle)))
+        elif transport == "peer":
+            # one-hop exchange kernels over mailboxes the ranks map from each other (include/tangram_hip.h: tg_comm_peer_create).
+            # Ranks of ONE process (the in-process communicator of the GPU tests) exchange raw device pointers, processes hipIpc handles.
+            same = bool(getattr(self.pycomm, "same_process", False))
+            cap = max(6 * self.eng.C + 64, 2 * (self.eng.K + 1024))           # the longest per-step vector; longer ones travel in pieces
+            buf = ct.create_string_buffer(64)
+            with (torch.cuda.device(self.eng.device) if self.eng.device.type == "cuda" else _Null()):
+                _capi.check(lib.tg_comm_peer_create(self.world, self.rank, cap, int(same), buf, ct.byref(handle)))
+                mine = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                on_dev = isinstance(self.pycomm, DistComm) and dist.get_backend(group) == "nccl"
+                if on_dev:
+                    mine = mine.to(self.eng.device)
+                outs = [torch.empty_like(mine) for _ in range(self.world)]
+                self.pycomm.all_gather(outs, mine)
+                allh = b"".join(bytes(o.cpu().numpy().tobytes()) for o in outs)
+                _capi.check(lib.tg_comm_peer_connect(handle, allh))
+                if hasattr(self.pycomm, "barrier"):
+                    self.pycomm.barrier()                                    # nobody pushes before everybody has mapped everybody
         else:
-            raise ValueError("transport must be 'auto', 'rccl' or 'callbacks'")
+            raise ValueError("transport must be 'auto', 'rccl', 'peer' or 'callbacks'")
         self._comm = handle
         self._attach()
+
+    def peer_check(self):
+        """Peer transport: raise if an exchange ever gave up waiting for a peer (bounded polls, TG_PEER_TIMEOUT_MS); synchronises."""
+        if self.transport != "peer" or not getattr(self, "_comm", None):
+            return
+        flag = ct.c_int(0)
+        with (torch.cuda.device(self.eng.device) if self.eng.device.type == "cuda" else _Null()):
+            _capi.check(self.eng._lib.tg_comm_peer_status(self._comm, ct.byref(flag)))
+        if flag.value:
+            raise RuntimeError("tangram_amd: a peer-memory exchange timed out waiting for another rank (results are invalid)")
 
     def _from_rank0(self, x, device):
         """`x` as held by rank 0, on every rank (float32 device tensor)."""
@@ -194,6 +238,7 @@ class ShardedMapperEngine:
         """This rank's block of the mapping only: (softmax(M)[:, lo:hi] as a device tensor, (lo, hi)[, filter]) -- nothing is
         gathered (config 4: the full mapping is 40 GB; 8 ranks each returning it would be 320 GB of host memory)."""
         lo, hi = shard_bounds(self.n_spots_total, self.world, self.rank, self.spatial)
+        self.peer_check()
         if with_filter:
             P_local, F = self.eng.result(with_filter=True)
             return P_local, (lo, hi), F
@@ -203,6 +248,7 @@ class ShardedMapperEngine:
         """The column blocks of softmax(M) of every rank -> [C, V_total] on every rank (+ the replicated filter).
         `host=True`: a NumPy array assembled block by block (one rank's block is broadcast at a time), so that no GPU ever holds
         more than its own block plus one peer's -- for problems whose full mapping does not fit beside the training state."""
+        self.peer_check()
         if with_filter:
             P_local, F = self.eng.result(with_filter=True)
         else:

@@ -14,8 +14,13 @@ class LocalGroup:
 
 
 class LocalComm:
+    same_process = True          # (peer transport: the ranks exchange raw device pointers instead of hipIpc handles)
+
     def __init__(self, group, rank):
         self.g, self.rank, self.world = group, rank, group.world
+
+    def barrier(self):
+        self.g.barrier.wait()
 
     def _sync(self, t):
         if t.is_cuda:

@@ -23,7 +23,7 @@ def _free_port():
 LAM_C = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.7, lambda_r=1e-3, lambda_count=0.5, lambda_f_reg=2.0)
 
 
-def _worker(rank, world, port, sim_path, outdir):
+def _worker(rank, world, port, sim_path, outdir, transport="callbacks"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,8 +36,8 @@ def _worker(rank, world, port, sim_path, outdir):
         data = orc.make_synthetic(C, K, V, seed=21)
         M0 = orc.reference_init_M(C, V, 5)
         lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
-        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam)
-        assert sh.transport == "callbacks"
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam, transport=transport)
+        assert sh.transport == transport
         n = 4
         hist = sh.eng.new_history(n)
         sh.run(n, 0.1, hist)               # ONE call of the C library: kernels + the three exchanges per step (gloo through callbacks)
@@ -45,23 +45,27 @@ def _worker(rank, world, port, sim_path, outdir):
         # MapperConstrained on shards: the filter F is replicated, its gradient comes from the all-reduced row sums
         M0c, F0c = orc.reference_init_MF_constrained(C, V, 5)
         shc = make_sharded(data["S"], data["G"], M0c, d=data["d"], F0=F0c, mode="constrained", device="cpu", precision="fp32",
-                           lambdas=LAM_C, target_count=40.0)
+                           lambdas=LAM_C, target_count=40.0, transport=transport)
         hc = shc.eng.new_history(n)
         shc.run(n, 0.1, hc)
         Pc, Fc = shc.result_full(with_filter=True)
         Gc = shc.project_full()
+        sh.peer_check(); shc.peer_check()      # (peer transport: no exchange ever gave up waiting)
         np.savez(os.path.join(outdir, f"sharded_{rank}.npz"), P=P.numpy(), hist=hist.numpy(), Pc=Pc.numpy(), Fc=Fc.numpy(),
                  hc=hc.numpy(), Gc=Gc.numpy())
     finally:
         dist.destroy_process_group()
 
 
-def test_two_shards_match_single_and_oracle(tmp_path):
+@pytest.mark.parametrize("transport", ["callbacks", "peer"])
+def test_two_shards_match_single_and_oracle(tmp_path, transport):
+    """transport "callbacks": gloo collectives called back from the C step; "peer": the library's own one-hop exchange kernels over
+    mailboxes the two processes map from each other (emulated build: POSIX shared memory stands in for hipIpc device memory)."""
     sim_path = build_sim()
     if sim_path is None:
         pytest.skip("host clang not available to build the emulator")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, sim_path, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, sim_path, str(tmp_path), transport), nprocs=2, join=True)
     z = np.load(tmp_path / "sharded_0.npz")
     z1 = np.load(tmp_path / "sharded_1.npz")
     for k in z.files:                                    # every rank holds the same global history, mapping, filter, projection
