@@ -149,14 +149,15 @@ int tg_comm_rccl_unique_id(const char* librccl_path, void* id128_out);
 int tg_comm_create_rccl(const char* librccl_path, const void* id128, int world, int rank, tg_comm** out);
 /* Peer memory (ABI version 5): the third transport.  Every rank owns a MAILBOX in its own HBM which every peer maps (hipIpc between the
  * processes of one node: xGMI stores; plain pointers between shards that live in one process); an exchange is ONE kernel per rank on
- * the handle's stream and ONE hop: push this rank's vector into every mailbox, raise a flag, wait for the peers' flags in the own
- * mailbox, sum in RANK ORDER (bit-identical on every rank) or copy out.  No collective library, no host code, no extra stream; its
- * latency is a kernel launch plus one xGMI write, not a ring of 2 (N - 1) hops.  tg_comm_peer_create allocates the mailbox (fine-
+ * the handle's stream and ONE hop: store this rank's vector into every mailbox as 8-byte {value, sequence number} granules (one
+ * write-through store each: no flag, no fence), poll the peers' granules in the own mailbox, sum in RANK ORDER (bit-identical on
+ * every rank) or copy out.  No collective library, no host code, no extra stream; its latency is a kernel launch plus one xGMI
+ * write, not a ring of 2 (N - 1) hops.  tg_comm_peer_create allocates the mailbox (fine-
  * grained device memory: the one allocation this library makes, owned by the communicator) and returns a 64-byte handle; gather the
  * handles of all ranks over any out-of-band channel (torch.distributed) and pass them, in rank order, to tg_comm_peer_connect.
  * capacity_floats: the longest vector moved in one piece (longer ones go in pieces); same_process != 0: the handle is a raw device
- * pointer (ranks are threads of one process on one GPU -- tests; give every rank its own stream: a rank's kernel waits for its peers'
- * kernels).  One handle per peer communicator; sharded steps through it cannot be captured into a HIP graph (the sequence number of
+ * pointer (ranks living in one process; every rank needs a stream -- and a hardware queue -- of its own: a rank's kernel waits for
+ * its peers' kernels).  One handle per peer communicator; sharded steps through it cannot be captured into a HIP graph (the sequence number of
  * an exchange is a launch argument).  A poll that does not meet its peers within TG_PEER_TIMEOUT_MS (environment, default 20 000)
  * gives up and sets a flag that tg_comm_peer_status reports: a lost peer costs a bounded wait, never a hang. */
 int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out);

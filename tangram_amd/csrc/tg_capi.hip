@@ -1509,7 +1509,7 @@ struct tg_comm {
     const char* (*p_errstr)(int);
     // peer-memory transport (tg_peer_exchange, tg_kernels.h): this rank's mailbox, every rank's mailbox as mapped here
     unsigned char* box; unsigned char* peer[TG_PEER_MAX];
-    size_t cap, box_bytes; int nchunk_cap; unsigned seq; int peer_mode, connected;   // peer_mode 0: off; 1: hipIpc handles; 2: raw pointers
+    size_t cap, box_bytes; unsigned seq; int peer_mode, connected;                   // peer_mode 0: off; 1: hipIpc handles; 2: raw pointers
     unsigned long long timeout_ticks;
     char shm_name[64];                                                               // (emulated build: the mailbox is a POSIX shm object)
 };
@@ -1544,7 +1544,6 @@ extern "C" int tg_comm_peer_create(int world, int rank, size_t capacity_floats, 
     memset(c, 0, sizeof *c);
     c->world = world; c->rank = rank;
     c->cap = rup(capacity_floats, TG_PEER_CHUNK);
-    c->nchunk_cap = (int)(c->cap / TG_PEER_CHUNK);
     c->box_bytes = tg_peer_box_bytes(world, c->cap);
     c->peer_mode = same_process ? 2 : 1;
     c->timeout_ticks = tg_peer_timeout_ticks();
@@ -1708,7 +1707,7 @@ static int tg_peer_exchange_go(tg_mapper* m, const float* send, float* recv, siz
         const size_t piece = (n - off < c->cap) ? n - off : c->cap;
         TgPeerArgs a;
         for (int r = 0; r < TG_PEER_MAX; ++r) a.box[r] = r < c->world ? c->peer[r] : nullptr;
-        a.world = c->world; a.rank = c->rank; a.cap = c->cap; a.nchunk_cap = c->nchunk_cap;
+        a.world = c->world; a.rank = c->rank; a.cap = c->cap;
         c->seq += 1;
         a.seq = c->seq; a.slot = (int)(c->seq & 1u);
         a.send = send + off; a.recv = recv + off; a.n = piece; a.gather = gather; a.ld = n; a.timeout_ticks = c->timeout_ticks;

@@ -2039,108 +2039,96 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
 // Peer-memory exchange: the third tg_comm transport (tg_capi.hip: tg_comm_peer_create / _connect).
 //   The three per-step exchanges of a spot shard are 8 KB - 1 MB vectors whose cost on a collective library is its fixed latency
 //   (a ring all-reduce on 8 ranks is 14 dependent hops).  Here an exchange is ONE kernel per rank and ONE hop: every rank owns a
-//   MAILBOX in its own HBM that every peer has mapped (hipIpc between processes of a node: xGMI stores; plain pointers between the
-//   in-process shards of the tests); a workgroup owns a chunk of the vector and
-//     1. pushes this rank's chunk into slot [generation & 1][this rank] of EVERY rank's mailbox (its own included),
-//     2. drains the stores (system-scope release fence + s_waitcnt vmcnt(0): MI355X_MICROARCH.md "Compiler hazard") and raises the
-//        chunk's flag [generation & 1][this rank][chunk] = sequence number in every mailbox,
-//     3. waits until the flags of all ranks for this chunk in its OWN mailbox carry the sequence number (bounded poll),
-//     4. all-reduce: sums the world copies of the chunk in RANK ORDER (every rank adds the same floats in the same order: the
-//        result is bit-identical on every rank, and equal to the callback transport's rank-order sum); all-gather: copies them out.
-//   Chunks are independent: no grid-wide barrier.  Two generations of slots suffice: a rank can be at most one exchange ahead of
-//   the slowest peer (it leaves exchange g only after every peer has pushed g, and a peer pushes g + 1 only after its own kernel of
-//   g has finished reading).  Sequence numbers only grow: flags never need clearing.
+//   MAILBOX in its own HBM that every peer has mapped (hipIpc between processes of a node: xGMI stores; plain pointers between
+//   shards inside one process).  The mailbox holds, per generation slot (2) and source rank, the vector as 8-byte GRANULES
+//   {float value, sequence number of the exchange}, each written by ONE naturally aligned write-through store (system-scope relaxed
+//   atomic: sc0 sc1) -- value and tag arrive together or not at all, so there is no flag, no fence and no barrier
+//   (MI355X_MICROARCH.md, "handoff-1to1": tagged granules cost half of payload + flag).  A thread
+//     1. reads its elements of this rank's vector and stores their granules into slot [seq & 1][this rank] of EVERY rank's mailbox
+//        (its own included), peers visited from rank + 1 on;
+//     2. polls the granules of the same elements from every rank in its OWN mailbox until their tag is this exchange's sequence
+//        number (bounded: a peer that never arrives costs TG_PEER_TIMEOUT_MS, raises the error word, and the kernel ends);
+//     3. all-reduce: adds the world values in RANK ORDER (every rank adds the same floats in the same order: bit-identical on every
+//        rank, and equal to the callback transport's rank-order sum); all-gather: copies them out.
+//   Elements are independent: no workgroup or grid barrier.  Two generation slots suffice: a rank leaves exchange g only after every
+//   peer has pushed g, and a peer pushes g + 1 only after its own kernel of g has finished reading, so nobody writes generation g + 2
+//   into a slot somebody still reads generation g from.  Sequence numbers only grow (the mailbox starts zeroed; the first is 1).
 // ----------------------------------------------------------------------------------------------
 #define TG_PEER_MAX 16
-#define TG_PEER_CHUNK 2048              // floats per workgroup (8 KB to each peer)
-#define TG_PEER_HDR 256                 // bytes in front of the flags: [0] error word (1: a poll timed out)
+#define TG_PEER_CHUNK 2048              // floats per workgroup
+#define TG_PEER_HDR 256                 // bytes in front of the granules: [0] error word (1: a poll timed out)
 #ifdef TG_SIM
 #include <chrono>
 #include <sched.h>
-TG_DEV void tg_sys_store_release(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
-TG_DEV unsigned tg_sys_load_acquire(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-TG_DEV void tg_sys_fence_release() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-TG_DEV void tg_sys_fence_acquire() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+TG_DEV void tg_sys_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+TG_DEV unsigned long long tg_sys_load_u64(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+TG_DEV void tg_sys_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 TG_DEV unsigned long long tg_wall_ticks() {      // 100 MHz like wall_clock64()
     return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
 }
 TG_DEV void tg_poll_pause() { sched_yield(); }
 #else
-TG_DEV void tg_sys_store_release(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-TG_DEV unsigned tg_sys_load_acquire(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-TG_DEV void tg_sys_fence_release() {
-    __atomic_thread_fence(__ATOMIC_RELEASE);            // (system scope: __threadfence_system)
-    __threadfence_system();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // never let the flag overtake the payload (the guide's compiler hazard)
-}
-TG_DEV void tg_sys_fence_acquire() { __threadfence_system(); }
+TG_DEV void tg_sys_store_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+TG_DEV unsigned long long tg_sys_load_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+TG_DEV void tg_sys_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 TG_DEV unsigned long long tg_wall_ticks() { return wall_clock64(); }
-TG_DEV void tg_poll_pause() { __builtin_amdgcn_s_sleep(8); }
+TG_DEV void tg_poll_pause() { __builtin_amdgcn_s_sleep(2); }
 #endif
 struct TgPeerArgs {
     unsigned char* box[TG_PEER_MAX];    // every rank's mailbox as mapped by THIS rank; box[rank] is its own
     int world, rank;
-    unsigned long long cap;             // floats of one (slot, rank) data region
-    int nchunk_cap;                     // flags of one (slot, rank)
+    unsigned long long cap;             // granules of one (slot, rank) region
     int slot; unsigned seq;
     const float* send; float* recv;     // all-reduce: in place (send == recv)
     unsigned long long n;               // floats (per rank)
     int gather; unsigned long long ld;  // gather: recv[r * ld + i]
-    unsigned long long timeout_ticks;   // bound of step 3 in 10-ns ticks
+    unsigned long long timeout_ticks;   // bound of a poll in 10-ns ticks
 };
-TG_HD size_t tg_peer_data_base(int world, int nchunk_cap) {
-    const size_t flags = (size_t)2 * world * nchunk_cap * 4;
-    return (TG_PEER_HDR + flags + 255) / 256 * 256;
-}
-TG_HD size_t tg_peer_box_bytes(int world, size_t cap) {
-    const int nchunk_cap = (int)((cap + TG_PEER_CHUNK - 1) / TG_PEER_CHUNK);
-    return tg_peer_data_base(world, nchunk_cap) + (size_t)2 * world * cap * 4;
+TG_HD size_t tg_peer_box_bytes(int world, size_t cap) { return TG_PEER_HDR + (size_t)2 * world * cap * 8; }
+// the value of granule *g once its tag is `seq` (0.f after a time-out, with the error word raised)
+TG_DEV float tg_peer_take(const unsigned long long* g, unsigned seq, unsigned long long timeout, unsigned* err) {
+    unsigned long long x = tg_sys_load_u64(g);
+    if ((unsigned)(x >> 32) != seq) {
+        const unsigned long long t0 = tg_wall_ticks();
+        do {
+            tg_poll_pause();
+            x = tg_sys_load_u64(g);
+            if ((unsigned)(x >> 32) == seq) break;
+            if (tg_wall_ticks() - t0 > timeout) { tg_sys_store_u32(err, 1u); return 0.f; }
+        } while (true);
+    }
+    return __builtin_bit_cast(float, (unsigned)x);
 }
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_peer_exchange(TgPeerArgs a) {
-    const int t = threadIdx.x, chunk = blockIdx.x;
-    const size_t lo = (size_t)chunk * TG_PEER_CHUNK;
-    const size_t hi = (lo + TG_PEER_CHUNK < a.n) ? lo + TG_PEER_CHUNK : (size_t)a.n;
-    const size_t dbase = tg_peer_data_base(a.world, a.nchunk_cap);
-    const size_t region = ((size_t)a.slot * a.world + a.rank) * a.cap;         // my data region in anybody's mailbox
-    const size_t flag_i = ((size_t)a.slot * a.world + a.rank) * a.nchunk_cap + chunk;
-    // 1. push (peers visited from rank + 1 on: at any moment the ranks write to different peers)
-    float mine[TG_PEER_CHUNK / 256];
+    constexpr int NJ = TG_PEER_CHUNK / 256;
+    const int t = threadIdx.x;
+    const size_t lo = (size_t)blockIdx.x * TG_PEER_CHUNK;
+    const size_t region = ((size_t)a.slot * a.world + a.rank) * a.cap;         // my region in anybody's mailbox
+    const unsigned long long tag = (unsigned long long)a.seq << 32;
+    // 1. push
+    float mine[NJ];
 #pragma unroll
-    for (int j = 0; j < TG_PEER_CHUNK / 256; ++j) { const size_t i = lo + t + 256 * (size_t)j; mine[j] = i < hi ? a.send[i] : 0.f; }
+    for (int j = 0; j < NJ; ++j) { const size_t i = lo + t + 256 * (size_t)j; mine[j] = i < a.n ? a.send[i] : 0.f; }
     for (int p = 0; p < a.world; ++p) {
-        const int dst_rank = (a.rank + 1 + p) % a.world;
-        float* dst = (float*)(a.box[dst_rank] + dbase) + region;
+        unsigned long long* dst = (unsigned long long*)(a.box[(a.rank + 1 + p) % a.world] + TG_PEER_HDR) + region;
 #pragma unroll
-        for (int j = 0; j < TG_PEER_CHUNK / 256; ++j) { const size_t i = lo + t + 256 * (size_t)j; if (i < hi) dst[i] = mine[j]; }
-    }
-    // 2. payload drained, then the flags
-    tg_sys_fence_release();
-    __syncthreads();
-    if (t < a.world) tg_sys_store_release((unsigned*)(a.box[t] + TG_PEER_HDR) + flag_i, a.seq);
-    // 3. this chunk of every rank has arrived in MY mailbox
-    if (t < a.world) {
-        const unsigned* f = (const unsigned*)(a.box[a.rank] + TG_PEER_HDR) + ((size_t)a.slot * a.world + t) * a.nchunk_cap + chunk;
-        const unsigned long long t0 = tg_wall_ticks();
-        while (tg_sys_load_acquire(f) != a.seq) {
-            if (tg_wall_ticks() - t0 > a.timeout_ticks) { *(volatile unsigned*)(a.box[a.rank]) = 1u; break; }
-            tg_poll_pause();
+        for (int j = 0; j < NJ; ++j) {
+            const size_t i = lo + t + 256 * (size_t)j;
+            if (i < a.n) tg_sys_store_u64(dst + i, tag | (unsigned long long)__builtin_bit_cast(unsigned, mine[j]));
         }
     }
-    __syncthreads();
-    tg_sys_fence_acquire();
-    // 4. rank-order sum / copy-out
-    const float* in = (const float*)(a.box[a.rank] + dbase) + (size_t)a.slot * a.world * a.cap;
-    if (a.gather) {
-        for (int r = 0; r < a.world; ++r)
+    // 2. + 3. take every rank's granules of my elements out of MY mailbox
+    const unsigned long long* in = (const unsigned long long*)(a.box[a.rank] + TG_PEER_HDR) + (size_t)a.slot * a.world * a.cap;
+    unsigned* err = (unsigned*)a.box[a.rank];
 #pragma unroll
-            for (int j = 0; j < TG_PEER_CHUNK / 256; ++j) { const size_t i = lo + t + 256 * (size_t)j; if (i < hi) a.recv[(size_t)r * a.ld + i] = in[(size_t)r * a.cap + i]; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < TG_PEER_CHUNK / 256; ++j) {
-            const size_t i = lo + t + 256 * (size_t)j;
-            if (i >= hi) continue;
-            float s = in[i];
-            for (int r = 1; r < a.world; ++r) s += in[(size_t)r * a.cap + i];
+    for (int j = 0; j < NJ; ++j) {
+        const size_t i = lo + t + 256 * (size_t)j;
+        if (i >= a.n) continue;
+        if (a.gather) {
+            for (int r = 0; r < a.world; ++r) a.recv[(size_t)r * a.ld + i] = tg_peer_take(in + (size_t)r * a.cap + i, a.seq, a.timeout_ticks, err);
+        } else {
+            float s = tg_peer_take(in + i, a.seq, a.timeout_ticks, err);
+            for (int r = 1; r < a.world; ++r) s += tg_peer_take(in + (size_t)r * a.cap + i, a.seq, a.timeout_ticks, err);
             a.recv[i] = s;
         }
     }
