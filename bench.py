@@ -112,6 +112,17 @@ MFMA_ONLY_PROBE = {"bf16x3": {"ms_per_gemm": 0.90, "frac_of_dense_peak": 0.84, "
                               "source": "profiles/r04/lab/lab.txt (VAR 1), cfg2 backward tile set incl. padding"}}
 
 
+# scripts/probes/cumask_step.py on MI355X (profiles/r05/run1_update_diet/cumask_step.txt): the kernels of the cfg2 iteration on CU-masked
+# streams -- what a backward || update overlap by CU partition would have to live on (the round-4 review's gate: the update on ~80 CUs
+# at >= 5.5 TB/s).  A CU moves <= ~37 GB/s of the update's stream whatever its instruction count (39.8 VALU per element since round 5).
+OVERLAP_GATE = {"update_TBps_by_cus": {"256": 6.24, "192": 5.64, "160": 5.09, "128": 4.33, "96": 3.39, "64": 2.40},
+                "bwd_gemm_ms_by_cus": {"256": 1.26, "192": 1.50, "160": 1.74, "128": 2.15, "96": 2.80},
+                "gate": "update on ~80 CUs >= 5.5 TB/s", "met": False,
+                "best_split": "128 / 128 CUs: 2.15 ms of backward GEMM beside 1.94 ms of update = 0.46 ms (12 %) saved in the ideal, before "
+                              "the fill / drain of a cell-band pipeline",
+                "source": "profiles/r05/run1_update_diet/cumask_step.txt"}
+
+
 def pmc_traffic(precision):
     """(HBM bytes per launch, note) from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE).  The table carries the fingerprint of the
@@ -464,7 +475,9 @@ def main():
             "mfma_only_probe": MFMA_ONLY_PROBE.get(precision),
             "note": "sequential_roof = (two GEMMs at the dense MFMA peak of the precision) + (update at 8 TB/s): what the three-kernel "
                     "chain could reach with every kernel AT its roof; overlap_bound = max(t_MFMA, t_HBM) of the whole iteration, "
-                    "reachable only if the phases overlapped (every overlap design measured slower, DESIGN.md section 6b)"}
+                    "reachable only if the phases overlapped (every overlap design measured slower: profiles/LABBOOK.md section 6b; "
+                    "round 5's gate on reviving them: overlap_gate below, DESIGN.md section 6)",
+            "overlap_gate": OVERLAP_GATE if (args.workload == "cfg2" and not args.shape) else None}
         target_its = 0.60 * HBM_PEAK / (bytes_alg / world)
         roof["target"] = {"definition": "north_star: >= 0.60 of the HBM roofline (8 TB/s) on the fused iteration",
                           "its": target_its, "ms_per_step": 1e3 / target_its, "met": bool(its >= target_its),
@@ -483,7 +496,7 @@ def main():
                        "effective_precision": eff_prec,
                        "parallelism": "single GPU" if world == 1 else
                        f"spots sharded over {world} ranks, 3 small exchanges/step issued by the library ({getattr(owner, 'transport', '?')}: "
-                       f"{'RCCL on the compute stream' if getattr(owner, 'transport', '') == 'rccl' else backend + ' through callbacks'})"},
+                       f"{ {'rccl': 'RCCL on the compute stream', 'peer': 'one-hop peer-memory exchange kernels on the compute stream'}.get(getattr(owner, 'transport', ''), backend + ' through callbacks') })"},
             "cell_spot_gene_per_s": its * C * K * V,
             "last_main_loss": main_loss,
             "roofline": roof,

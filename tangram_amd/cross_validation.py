@@ -50,24 +50,48 @@ def cv_data_gen(adata_sc, adata_sp, cv_mode="loo"):
         yield list(genes[:lo]) + list(genes[hi:]), list(genes[lo:hi])
 
 
+import logging
 from contextlib import nullcontext as _nullcontext
 
 from .batched import BATCH_MAX_ELEMENTS
 
 
-def _folds_resident(requested, n_src, n_sp, n_genes, device):
-    """How many folds' mappers may be RESIDENT at once.  `train_many` builds every mapper of a group before it trains any; a
-    mapper holds its logits, both Adam moments, the backward product and the GEMM workspace (~6 x cells x spots x 4 B, plus the
-    operand images of its genes).  The reference trains one fold at a time (utils.py:576-600), so a problem that fits there must
-    fit here: above the size where one mapping fills the GPU (`batched.BATCH_MAX_ELEMENTS`: such folds are not batched anyway)
-    the folds run one by one; below it the group is capped by the free device memory."""
+def _fold_footprint(n_src, n_sp, n_genes, precision, constrained):
+    """Device bytes ONE fold's mapper holds while it trains: what the C library itself asks for (`tg_query_sizes`: logits + both Adam
+    moments; workspace = operand images, the backward product, partial sums), plus the result and the initial-logit upload."""
+    import ctypes as ct
+
+    from . import _capi
+    cfg = _capi.TgConfig()
+    cfg.abi_version = _capi.TG_ABI_VERSION
+    cfg.mode = _capi.TG_MODE_CONSTRAINED if constrained else _capi.TG_MODE_MAPPER
+    cfg.precision = _capi.PRECISIONS[precision]
+    cfg.n_cells, cfg.n_genes, cfg.n_spots, cfg.n_spots_total = int(n_src), int(n_genes), int(n_sp), int(n_sp)
+    cfg.has_density, cfg.lambda_g1, cfg.lambda_d = 1, 1.0, 1.0
+    cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.999, 1e-8
+    sizes = _capi.TgSizes()
+    _capi.check(_capi.lib().tg_query_sizes(ct.byref(cfg), ct.byref(sizes)))
+    return int(sizes.state_bytes) + int(sizes.workspace_bytes) + 2 * 4 * int(n_src) * int(n_sp)
+
+
+def _folds_resident(requested, n_src, n_sp, n_genes, device, precision="bf16x3", constrained=False):
+    """How many folds' mappers may be RESIDENT at once.  `train_many` builds every mapper of a group before it trains any.  The
+    reference trains one fold at a time (utils.py:576-600), so a problem that fits there must fit here: above the size where one
+    mapping fills the GPU (`batched.BATCH_MAX_ELEMENTS`: such folds are not batched anyway) the folds run one by one; below it the
+    group is capped so that its footprint (`tg_query_sizes` per fold) stays within 0.6 of the free device memory.  The group size
+    never changes a fold's result (a batched fold is the bits of the same fold trained alone; tests/test_cross_val.py), only how many
+    share a launch; a reduction is logged."""
     if n_src * n_sp > BATCH_MAX_ELEMENTS:
         return 1
-    per_fold = 6 * 4 * n_src * (n_sp + 64) + 3 * 4 * (n_src + n_sp + 512) * (n_genes + 512)
-    if device.type == "cuda":
-        free, _ = torch.cuda.mem_get_info(device)
-        return max(1, min(requested, int(0.6 * free // per_fold)))
-    return requested
+    if device.type != "cuda":
+        return requested
+    per_fold = _fold_footprint(n_src, n_sp, n_genes, precision, constrained)
+    free, _ = torch.cuda.mem_get_info(device)
+    fit = max(1, int(0.6 * free // max(per_fold, 1)))
+    if fit < requested:
+        logging.info("tangram_amd.cross_val: folds_per_launch %d -> %d (%.1f GB per fold, %.1f GB of device memory free)",
+                     requested, fit, per_fold / 2 ** 30, free / 2 ** 30)
+    return min(requested, fit)
 
 
 def _to_device(x, device):
@@ -195,7 +219,8 @@ def cross_val(
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = list(range(rank, len(folds), world))                  # this rank's folds
     records = {}                                                 # fold -> (test_genes, test_score, train_score, df, prediction or None)
-    step = _folds_resident(max(1, int(folds_per_launch)), int(S_all.shape[0]), int(G_all.shape[0]), len(genes), device)
+    step = _folds_resident(max(1, int(folds_per_launch)), int(S_all.shape[0]), int(G_all.shape[0]), len(genes), device,
+                           precision=gemm_precision, constrained=(mode == "constrained"))
     for g0 in range(0, len(mine), step):
         ids = mine[g0:g0 + step]
         fold_group = [folds[i] for i in ids]

@@ -154,7 +154,10 @@ struct TgLayout {
 //     rounds of workgroups x (steps per piece x time per step + fixed cost per segment) + the write and re-read of the partial tiles
 // (tg_ghat_reduce streams them at ~1.5 TB/s) over the candidates: the tiles cut into s = 1, 2, ... equal ranges (no piece crosses
 // a tile), and r = 1, 2, 3 full rounds of the chip's workgroup slots (every CU the same number of steps whatever the tile count:
-// cfg2 has 79 x 2 tiles of 938 steps -- three ranges each were 474 workgroups = 1.85 rounds of 256, 128 pieces x 2 are 1.0).
+// cfg2's split-bf16 forward runs on 128 x 512 tiles: nvt = Vr / 128 = 80 spot tiles x nkt = 2 gene tiles of 938 steps -- three
+// equal ranges each were 480 workgroups = 1.875 rounds of 256; 128 pieces x 2 gene tiles are exactly one round, and 128 divides
+// 8 nvt = 640, which is what admits the stream-K candidate below.  On 256^2 tiles (nvt = 40, nkt = 4: plain bf16, fp32) the
+// candidate is 64 pieces x 4, 64 | 320.)
 static int tg_choose_units(int nvt, int nkt, int nsteps, int slots, int precision, int tile_edge, size_t tile_bytes) {
     double t_step = precision == TG_PREC_F32 ? 7.7 : 2.4;       // 256^2 tile, one contraction step (bf16: 64 elements)
     if (tile_edge != 256) t_step *= 0.5;                        // a quarter of the work on half a CU
@@ -185,6 +188,18 @@ static int tg_fwd_slots(int nvt, int nsteps, int units) {
     return mx;
 }
 
+// Does this configuration train on the clusters-mode kernels (tg_sc_forward / tg_sc_backward)?  ONE predicate for the precision
+// override at the top of tg_make_layout and for L->smallc: at most TG_SC_MAXC rows of M, one GPU, no spatial terms, rows within the
+// one-kernel update, tile_size not pinned.  (At most 32 cells are ONE cell tile, so the cell-band pipeline -- bands <= cell tiles --
+// never applies to such a problem: no separate bands condition.)
+static bool tg_is_clusters_problem(const tg_config* c) {
+    const bool spatial = c->lambda_neighborhood_g1 > 0.f || c->lambda_ct_islands > 0.f || c->lambda_getis_ord > 0.f || c->lambda_moran > 0.f ||
+                         c->lambda_geary > 0.f;
+    const int vtot = c->n_spots_total > 0 ? c->n_spots_total : c->n_spots;
+    return c->n_cells >= 1 && c->n_cells <= TG_SC_MAXC && !spatial && c->n_ranks == 0 && vtot == c->n_spots && c->n_spots <= TG_ROWPASS_MAX_V &&
+           c->tile_size == 0;
+}
+
 static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     if (!cfg_in) return tg_fail(TG_ERR_INVALID, "null config");
     // Clusters-mode problems (at most TG_SC_MAXC rows of M, one GPU, no spatial terms, tile_size not pinned) TRAIN on the exact-fp32
@@ -193,14 +208,7 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     // so that validation losses and projections come from the same numerical path as the training history (round 3 ran them at
     // the configured precision).  The EFFECTIVE precision is L->prec; tg_mapper_create stores it back into the handle's config.
     tg_config cfg_eff = *cfg_in;
-    {
-        const bool spatial0 = cfg_in->lambda_neighborhood_g1 > 0.f || cfg_in->lambda_ct_islands > 0.f || cfg_in->lambda_getis_ord > 0.f ||
-                              cfg_in->lambda_moran > 0.f || cfg_in->lambda_geary > 0.f;
-        const int vtot0 = cfg_in->n_spots_total > 0 ? cfg_in->n_spots_total : cfg_in->n_spots;
-        if (cfg_in->n_cells >= 1 && cfg_in->n_cells <= TG_SC_MAXC && !spatial0 && cfg_in->n_ranks == 0 && vtot0 == cfg_in->n_spots &&
-            cfg_in->n_spots <= TG_ROWPASS_MAX_V && cfg_in->tile_size == 0 && cfg_in->precision >= 0 && cfg_in->precision <= 2)
-            cfg_eff.precision = TG_PREC_F32;
-    }
+    if (tg_is_clusters_problem(cfg_in) && cfg_in->precision >= 0 && cfg_in->precision <= 2) cfg_eff.precision = TG_PREC_F32;
     const tg_config* cfg = &cfg_eff;
     if (cfg->abi_version != TG_ABI_VERSION) return tg_fail(TG_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, TG_ABI_VERSION);
     if (cfg->n_cells < 1 || cfg->n_genes < 1 || cfg->n_spots < 1) return tg_fail(TG_ERR_INVALID, "empty problem: C=%d K=%d V=%d", cfg->n_cells, cfg->n_genes, cfg->n_spots);
@@ -340,8 +348,7 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     L->o_gfrac = take((size_t)L->Kp * 4);
     L->o_rowent = take((size_t)L->Cp * 4);
     // small-C path (tg_kernels.h): single GPU, rows within the one-kernel update, no spatial terms (their extra gradient rides dGhat)
-    L->smallc = (L->C <= TG_SC_MAXC && !spatial && !L->sp_shard && cfg->n_ranks == 0 && L->Vtot == L->V && L->bands == 1 &&
-                 L->V <= TG_ROWPASS_MAX_V && cfg->tile_size == 0) ? 1 : 0;
+    L->smallc = (tg_is_clusters_problem(cfg) && L->bands == 1) ? 1 : 0;           // (bands == 1 always holds here: one cell tile)
     L->o_spotpart = take((size_t)L->nrb * 2 * 4);               // per-block sums of the spots' loss terms (32- or 64-spot blocks)
     if (L->smallc) {
         const size_t cm = (size_t)tg_sc_cm(L->C);
@@ -1567,9 +1574,8 @@ extern "C" int tg_comm_peer_create(int world, int rank, size_t capacity_floats, 
     // fine-grained device memory: peers write it and this GPU reads it while kernels are running (coarse-grained allocations are
     // only coherent at kernel boundaries).  The ONE device allocation of the library; it belongs to the communicator, not to a handle.
     void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, c->box_bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&p, c->box_bytes); }
-    if (e != hipSuccess) { delete c; return tg_fail(TG_ERR_HIP, "cannot allocate the %zu-byte mailbox (%s)", c->box_bytes, hipGetErrorString(e)); }
+    hipError_t e = hipExtMallocWithFlags(&p, c->box_bytes, hipDeviceMallocFinegrained);      // (no coarse-grained fallback: it would be incoherent)
+    if (e != hipSuccess) { (void)hipGetLastError(); delete c; return tg_fail(TG_ERR_HIP, "cannot allocate the %zu-byte fine-grained mailbox (%s)", c->box_bytes, hipGetErrorString(e)); }
     c->box = (unsigned char*)p;
     if ((e = hipMemset(p, 0, c->box_bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
         (void)hipFree(p); delete c; return tg_fail(TG_ERR_HIP, "clearing the mailbox failed (%s)", hipGetErrorString(e));
@@ -1703,6 +1709,8 @@ extern "C" void tg_comm_destroy(tg_comm* c) {
 static int tg_peer_exchange_go(tg_mapper* m, const float* send, float* recv, size_t n, int gather) {
     tg_comm* c = m->comm;
     if (!c->connected) return tg_fail(TG_ERR_STATE, "peer communicator not connected (tg_comm_peer_connect)");
+    if (tg_stream_capturing(m->stream))       // the sequence number of an exchange is a launch argument: a replay would find its granules already there
+        return tg_fail(TG_ERR_UNSUPPORTED, "a sharded step over the peer transport cannot be captured into a HIP graph");
     for (size_t off = 0; off < n; off += c->cap) {
         const size_t piece = (n - off < c->cap) ? n - off : c->cap;
         TgPeerArgs a;

@@ -275,7 +275,7 @@ TG_HD int tg_fwd_nseg(int vt, int nsteps, long long G, int units) {
 // their tiles at the same time (an XCD's 32 workgroups turn its L2 over every ~2 steps).
 //   pieces that do not cross tiles (units = nvt * s): the round-3 map -- an XCD holds spot tiles vt = x, x + 8, ... of ONE range;
 //   stream-K pieces: XCD x takes the pieces j = x, x + 8, x + 16, ...  Their start offsets inside a tile, j L mod nsteps with
-//   L = nvt nsteps / units, coincide exactly when units divides 8 nvt (cfg2: 80 spot tiles, 128 pieces, L = 5/8 of a tile): that
+//   L = nvt nsteps / units, coincide exactly when units divides 8 nvt (cfg2, 128 x 512 forward tiles: nvt = Vr / 128 = 80 spot tiles, 128 pieces, L = 5/8 of a tile): that
 //   is the shape of stream-K decompositions tg_choose_units considers.  (Contiguous ranges of pieces per XCD: the pieces of an
 //   XCD are then at 16 different offsets and S^T comes out of the MALL instead: forward 1.32 -> 1.29 ms instead of -> 1.23.)
 TG_HD int tg_fwd_units_grid(int units, int nkt) { return 8 * ((units + 7) / 8) * nkt; }

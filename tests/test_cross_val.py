@@ -92,6 +92,35 @@ def test_ten_fold_matches_the_sequential_procedure(sim, mode):
     np.testing.assert_allclose(cv["avg_train_score"], tr_ref.mean(), rtol=0, atol=1e-7)
 
 
+def test_scores_do_not_depend_on_how_many_folds_share_a_launch(sim):
+    """`folds_per_launch` (and the cap `_folds_resident` puts on it by free device memory) decides how many folds share a `tg_batch`,
+    never what a fold computes: the cross-validation scores and predictions for groups of 1, 3 and all folds are the same bits."""
+    import tangram_amd as tg
+    ad_sc, ad_sp = _adatas(C=60, K=7, V=40, seed=5)
+    kw = dict(cluster_label="subclass_label", mode="clusters", num_epochs=5, device="cpu", cv_mode="loo", return_gene_pred=True,
+              random_state=3, density_prior="rna_count_based", gemm_precision="fp32")
+    runs = [tg.cross_val(ad_sc, ad_sp, folds_per_launch=n, **kw) for n in (1, 3, 16)]
+    for cv, ad_ge, df in runs[1:]:
+        assert cv == runs[0][0]
+        np.testing.assert_array_equal(ad_ge.X, runs[0][1].X)
+        np.testing.assert_array_equal(df["score"].to_numpy(), runs[0][2]["score"].to_numpy())
+
+
+def test_fold_footprint_comes_from_the_library(sim):
+    """The resident-fold cap is sized by `tg_query_sizes` for the fold's shape (round-4 advisor finding: it was a hand formula)."""
+    import ctypes as ct
+    from tangram_amd import _capi
+    from tangram_amd.cross_validation import _fold_footprint
+    cfg = _capi.TgConfig()
+    cfg.abi_version, cfg.precision = _capi.TG_ABI_VERSION, _capi.PRECISIONS["bf16x3"]
+    cfg.n_cells, cfg.n_genes, cfg.n_spots, cfg.n_spots_total = 18, 250, 9852, 9852
+    cfg.has_density, cfg.lambda_g1, cfg.lambda_d, cfg.beta1, cfg.beta2, cfg.eps = 1, 1.0, 1.0, 0.9, 0.999, 1e-8
+    sizes = _capi.TgSizes()
+    assert _capi.lib().tg_query_sizes(ct.byref(cfg), ct.byref(sizes)) == 0
+    fp = _fold_footprint(18, 9852, 250, "bf16x3", False)
+    assert fp == sizes.state_bytes + sizes.workspace_bytes + 2 * 4 * 18 * 9852 and fp > 3 * 4 * 18 * 9852
+
+
 def test_argument_errors_are_those_of_map_cells_to_space(sim):
     import tangram_amd as tg
     ad_sc, ad_sp = _adatas(K=10)
