@@ -163,6 +163,12 @@ int tg_comm_create_rccl(const char* librccl_path, const void* id128, int world, 
 int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out);
 int tg_comm_peer_connect(tg_comm* c, const void* handles_world_x_64);
 int tg_comm_peer_status(tg_comm* c, int* timed_out);
+int tg_comm_peer_set_timeout_ms(tg_comm* c, double ms);      /* bound of the polls of the exchanges issued from now on */
+/* The two collectives a communicator of ANY transport runs between the kernels of a sharded step, as entry points of their own
+ * (enqueued on hip_stream; a caller can verify a transport on its topology before it trusts it with a run -- tangram_amd/sharded.py
+ * does so for the peer transport): in-place all-reduce(sum) of n floats; all-gather of n_per_rank floats into recv[rank * n_per_rank]. */
+int tg_comm_all_reduce_sum(tg_comm* c, float* buf_dev, size_t n, void* hip_stream);
+int tg_comm_all_gather(tg_comm* c, const float* send_dev, float* recv_dev, size_t n_per_rank, void* hip_stream);
 void tg_comm_destroy(tg_comm* c);
 
 int tg_abi_version(void);

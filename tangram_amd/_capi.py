@@ -68,7 +68,11 @@ def _declare(lib):
     lib.tg_comm_peer_create.argtypes = [i32, i32, ct.c_size_t, i32, vp, ct.POINTER(vp)]
     lib.tg_comm_peer_connect.argtypes = [vp, vp]
     lib.tg_comm_peer_status.argtypes = [vp, ct.POINTER(i32)]
-    for name in ("tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status"):
+    lib.tg_comm_peer_set_timeout_ms.argtypes = [vp, ct.c_double]
+    lib.tg_comm_all_reduce_sum.argtypes = [vp, vp, ct.c_size_t, vp]
+    lib.tg_comm_all_gather.argtypes = [vp, vp, vp, ct.c_size_t, vp]
+    for name in ("tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_peer_set_timeout_ms", "tg_comm_all_reduce_sum",
+                 "tg_comm_all_gather"):
         getattr(lib, name).restype = i32
     lib.tg_comm_destroy.argtypes = [vp]
     lib.tg_comm_destroy.restype = None
@@ -111,7 +115,8 @@ def _declare(lib):
 
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
-           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_destroy",
+           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_peer_set_timeout_ms",
+           "tg_comm_all_reduce_sum", "tg_comm_all_gather", "tg_comm_destroy",
            "tg_mapper_attach_comm", "tg_mapper_result",
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",
            "tg_cluster_aggregate", "tg_batch_query_bytes", "tg_batch_create", "tg_batch_step", "tg_batch_destroy", "tg_mapper_state", "tg_mapper_set_step",

@@ -1706,11 +1706,10 @@ extern "C" void tg_comm_destroy(tg_comm* c) {
 }
 
 // one exchange of the peer transport: pieces of at most `cap` floats, one kernel each (tg_peer_exchange)
-static int tg_peer_exchange_go(tg_mapper* m, const float* send, float* recv, size_t n, int gather) {
-    tg_comm* c = m->comm;
+static int tg_peer_exchange_go(tg_comm* c, tg_stream_t stream, const float* send, float* recv, size_t n, int gather) {
     if (!c->connected) return tg_fail(TG_ERR_STATE, "peer communicator not connected (tg_comm_peer_connect)");
-    if (tg_stream_capturing(m->stream))       // the sequence number of an exchange is a launch argument: a replay would find its granules already there
-        return tg_fail(TG_ERR_UNSUPPORTED, "a sharded step over the peer transport cannot be captured into a HIP graph");
+    if (tg_stream_capturing(stream))          // the sequence number of an exchange is a launch argument: a replay would find its granules already there
+        return tg_fail(TG_ERR_UNSUPPORTED, "an exchange over the peer transport cannot be captured into a HIP graph");
     for (size_t off = 0; off < n; off += c->cap) {
         const size_t piece = (n - off < c->cap) ? n - off : c->cap;
         TgPeerArgs a;
@@ -1719,28 +1718,46 @@ static int tg_peer_exchange_go(tg_mapper* m, const float* send, float* recv, siz
         c->seq += 1;
         a.seq = c->seq; a.slot = (int)(c->seq & 1u);
         a.send = send + off; a.recv = recv + off; a.n = piece; a.gather = gather; a.ld = n; a.timeout_ticks = c->timeout_ticks;
-        TG_LAUNCH(tg_peer_exchange, (piece + TG_PEER_CHUNK - 1) / TG_PEER_CHUNK, 1, 256, 0, m->stream, a);
+        TG_LAUNCH(tg_peer_exchange, (piece + TG_PEER_CHUNK - 1) / TG_PEER_CHUNK, 1, 256, 0, stream, a);
     }
     return tg_launch_failed() ? tg_launch_status() : TG_OK;
 }
 
-static int tg_comm_all_reduce(tg_mapper* m, float* buf, size_t n) {
-    tg_comm* c = m->comm;
-    int e;
-    if (c->peer_mode) { const int rc = tg_peer_exchange_go(m, buf, buf, n, 0); if (rc) return rc; e = 0; }
-    else if (c->nccl) e = c->p_allreduce(buf, buf, n, TG_NCCL_FLOAT, TG_NCCL_SUM, c->nccl, (void*)m->stream);
-    else e = c->ar(c->ctx, buf, n, (void*)m->stream);
+// The communicator's two collectives as entry points of their own (what tg_mapper_step issues between its kernels): in-place
+// all-reduce(sum) of n floats, all-gather of n floats per rank into recv[rank * n ...], enqueued on `hip_stream`.
+extern "C" int tg_comm_all_reduce_sum(tg_comm* c, float* buf_dev, size_t n, void* hip_stream) {
+    if (!c || !buf_dev) return tg_fail(TG_ERR_INVALID, "null communicator or buffer");
+    int e = 0;
+    if (c->peer_mode) { const int rc = tg_peer_exchange_go(c, (tg_stream_t)hip_stream, buf_dev, buf_dev, n, 0); if (rc) return rc; }
+    else if (c->nccl) e = c->p_allreduce(buf_dev, buf_dev, n, TG_NCCL_FLOAT, TG_NCCL_SUM, c->nccl, hip_stream);
+    else e = c->ar(c->ctx, buf_dev, n, hip_stream);
     if (e) return tg_fail(TG_ERR_HIP, "all-reduce of %zu floats failed with %d", n, e);
+    return TG_OK;
+}
+extern "C" int tg_comm_all_gather(tg_comm* c, const float* send_dev, float* recv_dev, size_t n_per_rank, void* hip_stream) {
+    if (!c || !send_dev || !recv_dev) return tg_fail(TG_ERR_INVALID, "null communicator or buffer");
+    int e = 0;
+    if (c->peer_mode) { const int rc = tg_peer_exchange_go(c, (tg_stream_t)hip_stream, send_dev, recv_dev, n_per_rank, 1); if (rc) return rc; }
+    else if (c->nccl) e = c->p_allgather(send_dev, recv_dev, n_per_rank, TG_NCCL_FLOAT, c->nccl, hip_stream);
+    else e = c->ag(c->ctx, send_dev, recv_dev, n_per_rank, hip_stream);
+    if (e) return tg_fail(TG_ERR_HIP, "all-gather of %zu floats per rank failed with %d", n_per_rank, e);
+    return TG_OK;
+}
+extern "C" int tg_comm_peer_set_timeout_ms(tg_comm* c, double ms) {
+    if (!c || !c->peer_mode) return tg_fail(TG_ERR_INVALID, "not a peer communicator");
+    c->timeout_ticks = (unsigned long long)((ms > 1.0 ? ms : 1.0) * 1e5);
+    return TG_OK;
+}
+
+static int tg_exchange_all_reduce(tg_mapper* m, float* buf, size_t n) {
+    const int rc = tg_comm_all_reduce_sum(m->comm, buf, n, (void*)m->stream);
+    if (rc) return rc;
     tg_prof_mark(m, "exchange_all_reduce");
     return TG_OK;
 }
-static int tg_comm_all_gather(tg_mapper* m, const float* send, float* recv, size_t n) {
-    tg_comm* c = m->comm;
-    int e;
-    if (c->peer_mode) { const int rc = tg_peer_exchange_go(m, send, recv, n, 1); if (rc) return rc; e = 0; }
-    else if (c->nccl) e = c->p_allgather(send, recv, n, TG_NCCL_FLOAT, c->nccl, (void*)m->stream);
-    else e = c->ag(c->ctx, send, recv, n, (void*)m->stream);
-    if (e) return tg_fail(TG_ERR_HIP, "all-gather of %zu floats per rank failed with %d", n, e);
+static int tg_exchange_all_gather(tg_mapper* m, const float* send, float* recv, size_t n) {
+    const int rc = tg_comm_all_gather(m->comm, send, recv, n, (void*)m->stream);
+    if (rc) return rc;
     tg_prof_mark(m, "exchange_all_gather");
     return TG_OK;
 }
@@ -1748,7 +1765,7 @@ static int tg_comm_all_gather(tg_mapper* m, const float* send, float* recv, size
 // gather every rank's (max, sum exp) block, merge; `hist_row`: also turn this rank's history row into the global one
 static int tg_exchange_row_stats(tg_mapper* m, float* hist_row) {
     const TgLayout& L = m->L;
-    int rc = tg_comm_all_gather(m, m->fp(L.o_rowpair), m->fp(L.o_gathered), L.pair_stride);
+    int rc = tg_exchange_all_gather(m, m->fp(L.o_rowpair), m->fp(L.o_gathered), L.pair_stride);
     if (rc) return rc;
     return tg_merge(m, m->fp(L.o_gathered), m->comm->world, /*finalize=*/true, /*want_pair=*/false, hist_row, m->comm->rank);
 }
@@ -1767,13 +1784,13 @@ extern "C" int tg_mapper_attach_comm(tg_mapper* m, tg_comm* comm) {
     if (L.sp_shard) {
         // the spatial terms see the whole spot graph: gather the blocks of G once (the references W G, |W G_k|^2 and the autocorrelation
         // indicators of G are constants of the run), like Ghat every iteration
-        int rcs = tg_comm_all_gather(m, m->fp(L.o_Gp), m->fp(L.o_Gfull), (size_t)L.Vmaxl * L.Kp);
+        int rcs = tg_exchange_all_gather(m, m->fp(L.o_Gp), m->fp(L.o_Gfull), (size_t)L.Vmaxl * L.Kp);
         if (rcs) return rcs;
         if ((rcs = tg_setup_spatial_derived(m))) return rcs;
         if (L.has_ac && (rcs = tg_setup_autocorr(m))) return rcs;
     }
     // set-up exchange: |G_k|^2 over all spots and the total of the density prior, then the softmax statistics of the initial logits
-    int rc = tg_comm_all_reduce(m, m->fp(L.o_gnorm2), (size_t)L.Kp + 1);
+    int rc = tg_exchange_all_reduce(m, m->fp(L.o_gnorm2), (size_t)L.Kp + 1);
     if (rc) return rc;
     if ((rc = tg_softmax_stats_from_scratch(m))) return rc;
     return tg_exchange_row_stats(m, nullptr);
@@ -1787,15 +1804,15 @@ static int tg_one_step_sharded(tg_mapper* m, float lr, float* hist_row) {
     int rc;
     if ((rc = tg_launch_forward<PR>(m))) return rc;
     if ((rc = tg_launch_ghat_stats(m))) return rc;
-    if ((rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
-    if (L.sp_shard && (rc = tg_comm_all_gather(m, m->fp(L.o_Ghat), m->fp(L.o_GhatFull), (size_t)L.Vmaxl * L.Kp))) return rc;   // spatial terms: all of Ghat
+    if ((rc = tg_exchange_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
+    if (L.sp_shard && (rc = tg_exchange_all_gather(m, m->fp(L.o_Ghat), m->fp(L.o_GhatFull), (size_t)L.Vmaxl * L.Kp))) return rc;   // spatial terms: all of Ghat
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;                                    // (coefficients; dGhat operand image)
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);                                                // X + row-dot partials of this rank's spots
     tg_prof_mark(m, "tg_bwd_kernel");
     tg_launch_rowsum(m, m->stream, 0, L.C);
     tg_prof_mark(m, "tg_rowsum_parts");
     if (tg_launch_failed()) return tg_launch_status();
-    if ((rc = tg_comm_all_reduce(m, m->fp(L.o_rowq), (size_t)(L.full ? TGP1_N : 1) * L.C))) return rc;   // E3: row dots (+ regulariser row sums)
+    if ((rc = tg_exchange_all_reduce(m, m->fp(L.o_rowq), (size_t)(L.full ? TGP1_N : 1) * L.C))) return rc;   // E3: row dots (+ regulariser row sums)
     if ((rc = tg_launch_update(m, lr, false))) return rc;       // Adam; local (max, sum exp); deferred history row by its extra workgroup
     if (L.full) {                                               // the row sums are global now: every rank adds the same scalars
         tg_launch_hist_regs(m, m->stream, hist_row);
@@ -1995,7 +2012,7 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
     }
     if (rc) return rc;
     if ((rc = tg_launch_ghat_stats(m, true))) return rc;
-    if (m->comm && (rc = tg_comm_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;      // per-gene sums over all spots
+    if (m->comm && (rc = tg_exchange_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;      // per-gene sums over all spots
     TG_LAUNCH(tg_row_entropy, L.C, 1, 256, 64, m->stream, (const float*)(m->st + L.s_M), (const float*)m->fp(L.o_rshift),
               (const float*)m->fp(L.o_rinvz), L.V, L.Vp, m->fp(L.o_rowent));
     TgValArgs a;
@@ -2008,7 +2025,7 @@ extern "C" int tg_mapper_validate(tg_mapper* m, float* out4_dev) {
         // buffer [2][Kp] (rewritten by the loss kernels of the next step); Kp >= 128, so 64 + Kp floats fit.
         a.part = m->fp(L.o_coef); a.partial = 1;
         TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);
-        if ((rc = tg_comm_all_reduce(m, a.part, (size_t)64 + L.Kp))) return rc;
+        if ((rc = tg_exchange_all_reduce(m, a.part, (size_t)64 + L.Kp))) return rc;
         a.partial = 0;
     }
     TG_LAUNCH(tg_val_finalize, 1, 1, 1024, 64, m->stream, a);

@@ -12,9 +12,12 @@ exchanges -- is issued by the C library inside `tg_mapper_step` (include/tangram
   * transport "rccl": the library binds librccl.so itself and calls ncclAllReduce / ncclAllGather on the handle's stream, between
     its own kernels: no Python, no second stream and no event between a kernel and the collective that consumes its output.
     The communicator is bootstrapped with one 128-byte broadcast over torch.distributed.
-  * transport "peer" (round 5, opt-in: `transport="peer"` or TG_SHARD_TRANSPORT=peer): no collective library at all -- every rank owns a
-    mailbox in its HBM that its peers map (hipIpc), an exchange is ONE kernel on the handle's stream and ONE xGMI hop (push to every
-    mailbox, flag, wait for the peers' flags, sum in rank order): the latency of a kernel launch, not of a 2 (N - 1)-hop ring.
+  * transport "peer" (round 5): no collective library at all -- every rank owns a mailbox in its HBM that its peers map (hipIpc), an
+    exchange is ONE kernel on the handle's stream and ONE xGMI hop (8-byte {value, sequence number} granules stored into every
+    mailbox, polled in the own one, summed in rank order): the latency of a kernel launch, not of a 2 (N - 1)-hop ring.
+    `transport="auto"` (the default) on an nccl group whose ranks share ONE node sets it up, runs a self-test against the group's
+    own all-reduce / all-gather on this very topology ("peer_checked"), and -- all ranks agreeing by an all-reduce of their
+    verdicts -- uses it; any failure (mailbox allocation, hipIpc mapping, a wrong or late result) falls back to "rccl", logged.
   * transport "callbacks": the library calls back into this module, which runs the collective through any object with
     `all_reduce(t)` / `all_gather_into_tensor(out, t)` (torch.distributed with gloo in the CPU tests, an in-process communicator
     for several shards of one GPU in the GPU tests).
@@ -64,6 +67,16 @@ class DistComm:
 
     def barrier(self):
         dist.barrier(group=self.group)
+
+
+def _single_node(group, device):
+    """Do all ranks of the group run on one host?  (hipIpc mailboxes need it.)"""
+    import socket
+    import zlib
+    h = float(zlib.crc32(socket.gethostname().encode()) % (1 << 23))
+    t = torch.tensor([h, -h], dtype=torch.float32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t[0].item() == h and -t[1].item() == h)
 
 
 def shard_bounds(n, world, rank, blocks=False):
@@ -117,12 +130,21 @@ class ShardedMapperEngine:
         self.n_spots_total = int(n_spots_total)
         lib = self.eng._lib
         if transport == "auto":
-            transport = os.environ.get("TG_SHARD_TRANSPORT", "auto")      # (bench / experiments: "peer", "rccl", "callbacks")
-        if transport == "auto":
+            transport = os.environ.get("TG_SHARD_TRANSPORT", "auto")      # (experiments: "peer", "peer_checked", "rccl", "callbacks")
+        fallback = None
+        if transport in ("auto", "peer_checked"):
             is_nccl = comm is None and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
-            transport = "rccl" if (is_nccl and not _capi.is_emulated() and self.eng.device.type == "cuda") else "callbacks"
-        self.transport = transport
+            base = "rccl" if (is_nccl and not _capi.is_emulated() and self.eng.device.type == "cuda") else "callbacks"
+            # Default on an nccl group of ONE node: the peer transport, IF its self-test on this very topology agrees with the
+            # group's own collectives (every rank decides the same, by an all-reduce of the verdicts); otherwise RCCL.
+            if transport == "auto":
+                transport = "peer_checked" if (base == "rccl" and self.world > 1 and self.world <= 16 and _single_node(group, self.eng.device)) else base
+            fallback = base
         self._error = None
+        self._init_transport(lib, group, transport, comm, fallback)
+
+    def _init_transport(self, lib, group, transport, comm, fallback):
+        self.transport = transport
         handle = ct.c_void_p()
         if transport == "rccl":
             uid = torch.zeros(128, dtype=torch.uint8)
@@ -141,28 +163,106 @@ class ShardedMapperEngine:
             self._cb_ar = _capi.ALL_REDUCE_FN(self._cb_all_reduce)       # (kept alive: the C side stores the function pointers)
             self._cb_ag = _capi.ALL_GATHER_FN(self._cb_all_gather)
             _capi.check(lib.tg_comm_create_callbacks(self.world, self.rank, self._cb_ar, self._cb_ag, None, ct.byref(handle)))
-        elif transport == "peer":
+        elif transport in ("peer", "peer_checked"):
             # one-hop exchange kernels over mailboxes the ranks map from each other (include/tangram_hip.h: tg_comm_peer_create).
-            # Ranks of ONE process (the in-process communicator of the GPU tests) exchange raw device pointers, processes hipIpc handles.
-            same = bool(getattr(self.pycomm, "same_process", False))
-            cap = max(6 * self.eng.C + 64, 2 * (self.eng.K + 1024))           # the longest per-step vector; longer ones travel in pieces
-            buf = ct.create_string_buffer(64)
-            with (torch.cuda.device(self.eng.device) if self.eng.device.type == "cuda" else _Null()):
-                _capi.check(lib.tg_comm_peer_create(self.world, self.rank, cap, int(same), buf, ct.byref(handle)))
-                mine = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-                on_dev = isinstance(self.pycomm, DistComm) and dist.get_backend(group) == "nccl"
-                if on_dev:
-                    mine = mine.to(self.eng.device)
-                outs = [torch.empty_like(mine) for _ in range(self.world)]
-                self.pycomm.all_gather(outs, mine)
-                allh = b"".join(bytes(o.cpu().numpy().tobytes()) for o in outs)
-                _capi.check(lib.tg_comm_peer_connect(handle, allh))
-                if hasattr(self.pycomm, "barrier"):
-                    self.pycomm.barrier()                                    # nobody pushes before everybody has mapped everybody
+            # "peer_checked": only after a self-test against the process group's own collectives; else (collectively) fall back.
+            handle = self._make_peer_comm(lib, group, selftest=(transport == "peer_checked"))
+            if handle is None:
+                if transport == "peer":
+                    raise RuntimeError("tangram_amd: the peer-memory transport could not be set up on this node (see the log)")
+                return self._init_transport(lib, group, fallback, comm, None)
+            self.transport = "peer"
         else:
-            raise ValueError("transport must be 'auto', 'rccl', 'peer' or 'callbacks'")
+            raise ValueError("transport must be 'auto', 'rccl', 'peer', 'peer_checked' or 'callbacks'")
         self._comm = handle
         self._attach()
+
+    # -- peer transport set-up (collective; every step's verdict is agreed on by all ranks before anybody goes on) ---------------
+    def _all_agree(self, ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32)
+        if isinstance(self.pycomm, DistComm) and dist.get_backend(self.group) == "nccl":
+            t = t.to(self.eng.device)
+        if isinstance(self.pycomm, DistComm):
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(t.item() > 0.5)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.pycomm.all_gather(outs, t)
+        return all(bool(o.item() > 0.5) for o in outs)
+
+    def _make_peer_comm(self, lib, group, selftest):
+        import logging
+        log = logging.getLogger("tangram_amd")
+        dev = self.eng.device
+        same = bool(getattr(self.pycomm, "same_process", False))
+        cap = max(6 * self.eng.C + 64, 2 * (self.eng.K + 1024))               # the longest per-step vector; longer ones travel in pieces
+        handle, ok, why = ct.c_void_p(), True, ""
+        ctx = torch.cuda.device(dev) if dev.type == "cuda" else _Null()
+        with ctx:
+            buf = ct.create_string_buffer(64)
+            try:
+                _capi.check(lib.tg_comm_peer_create(self.world, self.rank, cap, int(same), buf, ct.byref(handle)))
+            except Exception as e:        # noqa: BLE001
+                ok, why = False, f"create: {e}"
+            if not self._all_agree(ok):
+                log.info("tangram_amd: peer transport not available (%s)", why or "another rank failed to create its mailbox")
+                if handle:
+                    lib.tg_comm_destroy(handle)
+                return None
+            mine = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            on_dev = isinstance(self.pycomm, DistComm) and dist.get_backend(group) == "nccl"
+            if on_dev:
+                mine = mine.to(dev)
+            outs = [torch.empty_like(mine) for _ in range(self.world)]
+            self.pycomm.all_gather(outs, mine)
+            allh = b"".join(bytes(o.cpu().numpy().tobytes()) for o in outs)
+            try:
+                _capi.check(lib.tg_comm_peer_connect(handle, allh))
+            except Exception as e:        # noqa: BLE001
+                ok, why = False, f"connect: {e}"
+            if not self._all_agree(ok):
+                log.info("tangram_amd: peer transport not available (%s)", why or "another rank could not map the mailboxes")
+                lib.tg_comm_destroy(handle)
+                return None
+            if hasattr(self.pycomm, "barrier"):
+                self.pycomm.barrier()                                        # nobody pushes before everybody has mapped everybody
+            if selftest:
+                try:
+                    ok = self._peer_selftest(lib, handle, cap)
+                    why = "" if ok else "self-test: results differ from the process group's collectives"
+                except Exception as e:    # noqa: BLE001
+                    ok, why = False, f"self-test: {e}"
+                if not self._all_agree(ok):
+                    log.warning("tangram_amd: peer transport failed its self-test on this node (%s); using %s", why or "on another rank", "the process group's transport")
+                    self.eng._sync()
+                    lib.tg_comm_destroy(handle)
+                    return None
+                log.info("tangram_amd: peer-memory transport verified on this node (%d ranks)", self.world)
+        return handle
+
+    def _peer_selftest(self, lib, handle, cap):
+        """A few exchanges of the sizes a step moves (and one longer than the mailbox: pieces), against torch.distributed's own
+        all-reduce / all-gather on the same vectors; polls bounded to 3 s while testing."""
+        dev = self.eng.device
+        _capi.check(lib.tg_comm_peer_set_timeout_ms(handle, 3000.0))
+        stream = self.eng._hip_stream
+        good = True
+        for i, n in enumerate((257, 2 * self.eng.K + 64, self.eng.C, 2 * self.eng.C + 64, cap + 4099)):
+            g = torch.Generator(device="cpu").manual_seed(1000 * i + self.rank)
+            x = torch.randn(n, generator=g, dtype=torch.float32).to(dev)
+            ref = x.clone()
+            self.pycomm.all_reduce(ref)
+            got = x.clone()
+            _capi.check(lib.tg_comm_all_reduce_sum(handle, got.data_ptr(), n, stream))
+            outs = torch.empty(self.world * n, dtype=torch.float32, device=dev)
+            _capi.check(lib.tg_comm_all_gather(handle, x.data_ptr(), outs.data_ptr(), n, stream))
+            ref_g = torch.empty(self.world * n, dtype=torch.float32, device=dev)
+            self.pycomm.all_gather_into_tensor(ref_g, x)
+            self.eng._sync()
+            good = good and bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-5)) and bool(torch.equal(outs, ref_g))
+        flag = ct.c_int(0)
+        _capi.check(lib.tg_comm_peer_status(handle, ct.byref(flag)))
+        _capi.check(lib.tg_comm_peer_set_timeout_ms(handle, float(os.environ.get("TG_PEER_TIMEOUT_MS", "20000"))))
+        return good and not flag.value
 
     def peer_check(self):
         """Peer transport: raise if an exchange ever gave up waiting for a peer (bounded polls, TG_PEER_TIMEOUT_MS); synchronises."""

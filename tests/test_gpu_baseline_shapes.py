@@ -103,7 +103,7 @@ def _peer_problem(constrained):
     return data, orc.reference_init_M(C, V, 5), {}, PEER_LAM
 
 
-def _peer_worker(rank, world, port, outdir, constrained):
+def _peer_worker(rank, world, port, outdir, constrained, transport="peer"):
     """One PROCESS per rank, all on cuda:0: the mailboxes cross the process boundary as hipIpc handles; gloo only bootstraps."""
     import os
     import torch
@@ -116,8 +116,8 @@ def _peer_worker(rank, world, port, outdir, constrained):
         from tangram_amd.sharded import make_sharded
         data, M0, kw, lam = _peer_problem(constrained)
         n = PEER_SHAPE[3]
-        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision="bf16x3", lambdas=lam, transport="peer", **kw)
-        assert sh.transport == "peer"
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision="bf16x3", lambdas=lam, transport=transport, **kw)
+        assert sh.transport == "peer"           # ("peer_checked": the set-up's self-test against gloo's collectives passed)
         hist = sh.eng.new_history(n)
         sh.run(n, 0.1, hist, 0)
         torch.cuda.synchronize()
@@ -130,13 +130,16 @@ def _peer_worker(rank, world, port, outdir, constrained):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,constrained", [(2, False), (3, False), (4, False), (2, True)])
-def test_peer_transport_over_hip_ipc_equals_the_callback_transport(tmp_path, world, constrained):
+@pytest.mark.parametrize("world,constrained,transport", [(2, False, "peer"), (3, False, "peer"), (4, False, "peer"), (2, True, "peer"),
+                                                         (2, False, "peer_checked")])
+def test_peer_transport_over_hip_ipc_equals_the_callback_transport(tmp_path, world, constrained, transport):
     """The third transport (tg_comm_peer_*: ONE exchange kernel per rank -- write-through stores into every rank's mailbox, flag, wait
     for the peers' flags, sum in rank order) in its deployment form, as far as a 1-GPU box can show it: `world` PROCESSES share
     cuda:0, map each other's mailboxes through hipIpcGetMemHandle / hipIpcOpenMemHandle and step the sharded C schedule.  Reference:
     the callback transport on the same shards (threads of THIS process, tests/local_comm.py), which also sums the ranks' vectors in
     rank order -- so history, logits and mapping must agree BIT FOR BIT, and the global history is the same on every rank.
+    "peer_checked" = what `transport="auto"` does on an nccl group of one node: set-up + a self-test against the process group's own
+    collectives (gloo here), all ranks agreeing on the verdict, before the transport is trusted with the run.
     (Ranks as threads of one process cannot test the peer kernels reliably: a rank's exchange kernel waits for its peers' kernels, and
     two streams of one process may share a hardware queue -- measured: the first such case timed out, profiles/r05/run2_peer.)"""
     import socket
@@ -157,7 +160,7 @@ def test_peer_transport_over_hip_ipc_equals_the_callback_transport(tmp_path, wor
     ref = run_ranks(world, rank_fn)
     torch.cuda.synchronize()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_peer_worker, args=(world, port, str(tmp_path), constrained), nprocs=world, join=True)
+    mp.spawn(_peer_worker, args=(world, port, str(tmp_path), constrained, transport), nprocs=world, join=True)
     for r in range(world):
         z = np.load(tmp_path / f"peer_{r}.npz")
         for k in ("hist", "M", "P"):

@@ -37,7 +37,7 @@ def _worker(rank, world, port, sim_path, outdir, transport="callbacks"):
         M0 = orc.reference_init_M(C, V, 5)
         lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
         sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam, transport=transport)
-        assert sh.transport == transport
+        assert sh.transport == ("peer" if transport == "peer_checked" else transport)
         n = 4
         hist = sh.eng.new_history(n)
         sh.run(n, 0.1, hist)               # ONE call of the C library: kernels + the three exchanges per step (gloo through callbacks)
@@ -57,10 +57,11 @@ def _worker(rank, world, port, sim_path, outdir, transport="callbacks"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transport", ["callbacks", "peer"])
+@pytest.mark.parametrize("transport", ["callbacks", "peer", "peer_checked"])
 def test_two_shards_match_single_and_oracle(tmp_path, transport):
     """transport "callbacks": gloo collectives called back from the C step; "peer": the library's own one-hop exchange kernels over
-    mailboxes the two processes map from each other (emulated build: POSIX shared memory stands in for hipIpc device memory)."""
+    mailboxes the two processes map from each other (emulated build: POSIX shared memory stands in for hipIpc device memory);
+    "peer_checked": the same after the set-up's self-test against the group's own collectives (what "auto" does on an nccl group)."""
     sim_path = build_sim()
     if sim_path is None:
         pytest.skip("host clang not available to build the emulator")
