@@ -15,10 +15,17 @@ echo "== bench default"; SECONDS=0; timeout 1200 python bench.py > $O/bench_cfg2
 for W in cfg5a cfg5b cfg4; do
   echo "== bench $W"; timeout 900 python bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline --no-alt > $O/bench_$W.json 2> $O/bench_$W.err; echo "rc=$?"
 done
-echo "== 2-rank gloo smoke"; TG_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err; echo "rc=$?"; tail -c 300 $O/bench_2rank_gloo.json
+for T in callbacks peer_checked; do   # two ranks sharing the one GPU (gloo bootstraps): the callback transport, and the peer transport behind its self-test
+  echo "== 2-rank gloo smoke, transport $T"; TG_BENCH_BACKEND=gloo TG_SHARD_TRANSPORT=$T timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench_2rank_$T.json 2> $O/bench_2rank_$T.err; echo "rc=$?"; tail -c 200 $O/bench_2rank_$T.json
+done
+echo "== shard proxy"; timeout 600 python scripts/bench_shard_proxy.py > $O/shard.json 2> $O/shard.err; echo "rc=$?"
+echo "== batched folds"; timeout 600 python scripts/bench_batched.py --no-e2e --batches 8,16 > $O/batched.json 2> $O/batched.err; echo "rc=$?"; tail -c 400 $O/batched.json
 echo "== rocprof of the default command (shortened)"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-alt > $O/rocprof.log 2>&1; echo "rocprof rc=$?"
+for W in cfg5a cfg5b cfg4; do
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W -o r -- python $R/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-alt > $O/rocprof_$W.log 2>&1; echo "rocprof $W rc=$?"
+done
 cd $R
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -size +1M -delete
 python - $O <<'PY'
