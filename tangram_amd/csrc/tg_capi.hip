@@ -2162,6 +2162,14 @@ extern "C" int tg_debug_fwd_cover(const tg_config* cfg, long long* out) {
     out[0] = grid; out[1] = working; out[2] = lo; out[3] = hi; out[4] = most_seg; out[5] = L.nsplit;
     return TG_OK;
 }
+// TEST HOOK: Adam's square root and divisions as the update kernels evaluate them (tg_device.h: tg_sqrt_cr, tg_div_fr, tg_div_by):
+// out[0..n) = sqrt(a), out[n..2n) = a / b, out[2n..3n) = a / bc (device arrays; enqueued on hip_stream)
+extern "C" int tg_debug_adam_math(const float* a_dev, const float* b_dev, float bc, float* out_dev, long long n, void* hip_stream) {
+    if (!a_dev || !b_dev || !out_dev || n < 1) return tg_fail(TG_ERR_INVALID, "null argument");
+    TG_LAUNCH(tg_adam_math_probe, (n + 255) / 256, 1, 256, 0, (tg_stream_t)hip_stream, a_dev, b_dev, bc, out_dev, n);
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
 // the launch geometry tg_make_layout derives from a configuration: out[0..7] = tile edge, cell tiles, spot tiles, gene tiles,
 // forward splits, forward on 128 x 512 tiles (0/1), cell bands, clusters-mode kernels (0/1)
 extern "C" int tg_debug_layout(const tg_config* cfg, int* out) {

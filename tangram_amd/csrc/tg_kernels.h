@@ -1814,6 +1814,15 @@ TG_DEV void tg_row_stats_out(float tmax, float tsum, float* red, const TgUpdateA
     }
 }
 
+// TEST HOOK (tg_debug_adam_math, tests/test_gpu_parity.py): the three helpers on arrays, so that a test can hold them to IEEE results
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_adam_math_probe(const float* a, const float* b, float bc, float* out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = tg_sqrt_cr(a[i]);
+    out[n + i] = tg_div_fr(a[i], b[i]);
+    out[2 * n + i] = tg_div_by(a[i], bc, 1.f / bc);
+}
+
 // NT = 256 threads per cell; 1 024 for a handful of long rows (clusters mode beyond 16 384 spots: with 18 workgroups the kernel is
 // one dependent chain of V / (4 NT) trips per thread -- 81 us at 50 000 spots with 256 threads)
 template <bool FULL, bool X16, bool STREAM, int NT = 256>
@@ -2063,6 +2072,7 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
 TG_DEV void tg_sys_store_u64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 TG_DEV unsigned long long tg_sys_load_u64(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 TG_DEV void tg_sys_store_u32(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+TG_DEV unsigned tg_sys_load_u32(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 TG_DEV unsigned long long tg_wall_ticks() {      // 100 MHz like wall_clock64()
     return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
 }
@@ -2071,6 +2081,7 @@ TG_DEV void tg_poll_pause() { sched_yield(); }
 TG_DEV void tg_sys_store_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 TG_DEV unsigned long long tg_sys_load_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 TG_DEV void tg_sys_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+TG_DEV unsigned tg_sys_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 TG_DEV unsigned long long tg_wall_ticks() { return wall_clock64(); }
 TG_DEV void tg_poll_pause() { __builtin_amdgcn_s_sleep(2); }
 #endif
@@ -2117,9 +2128,11 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_peer_exchange(TgPeerArgs a) {
             if (i < a.n) tg_sys_store_u64(dst + i, tag | (unsigned long long)__builtin_bit_cast(unsigned, mine[j]));
         }
     }
-    // 2. + 3. take every rank's granules of my elements out of MY mailbox
+    // 2. + 3. take every rank's granules of my elements out of MY mailbox.  Once a poll has timed out (error word raised) a peer is
+    // gone: later exchanges do not wait again -- the run ends quickly with garbage and tg_comm_peer_status says why.
     const unsigned long long* in = (const unsigned long long*)(a.box[a.rank] + TG_PEER_HDR) + (size_t)a.slot * a.world * a.cap;
     unsigned* err = (unsigned*)a.box[a.rank];
+    if (tg_sys_load_u32(err) != 0u) a.timeout_ticks = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const size_t i = lo + t + 256 * (size_t)j;

@@ -18,7 +18,7 @@ def test_native_library_is_the_one_running():
     from tangram_amd import _capi
     assert torch.cuda.is_available()
     assert not _capi.is_emulated()
-    assert _capi.lib().tg_abi_version() == _capi.TG_ABI_VERSION == 4
+    assert _capi.lib().tg_abi_version() == _capi.TG_ABI_VERSION == 5
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
@@ -718,3 +718,51 @@ def test_device_initialiser_on_the_gpu():
     P1, h1 = Mapper(data["S"], data["G"], random_state=9, init="device", **kw).train(8, print_each=None)
     P2, _ = Mapper(data["S"], data["G"], random_state=9, init="device", **kw).train(8, print_each=None)
     assert np.array_equal(P1, P2) and h1["main_loss"][-1] > h1["main_loss"][0]
+
+
+def test_adam_square_root_and_divisions_against_ieee():
+    """The update kernels evaluate Adam's `sqrt(v) / bias_correction2_sqrt + eps` and `m / denom` (torch `_single_tensor_adam`) with
+    cheap sequences instead of hipcc's IEEE ones (tg_device.h, round 5): `tg_sqrt_cr` (v_rsq_f32 + a Newton step with fma residuals)
+    and `tg_div_by` (multiplication by the correctly rounded reciprocal + one residual correction) are held to the correctly
+    rounded IEEE results EXACTLY over the range Adam's second moment lives in; `tg_div_fr` (v_rcp_f32 + one residual correction) to
+    the IEEE quotient within 1 ulp, equal in all but a small fraction of the cases.  Zero, denormal and infinite arguments of the
+    square root come back as they are (sqrt of a denormal is <= 1.1e-19: it vanishes against eps in the denominator)."""
+    import ctypes as ct
+    from tangram_amd import _capi
+    lib = _capi.lib()
+    lib.tg_debug_adam_math.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_float, ct.c_void_p, ct.c_longlong, ct.c_void_p]
+    lib.tg_debug_adam_math.restype = ct.c_int
+    rng = np.random.default_rng(7)
+    n = 1 << 21
+    # second moments: squares of gradients over 30 decades, plus the special values; first moments / denominators likewise
+    a = np.exp(rng.uniform(np.log(1e-36), np.log(1e30), n)).astype(np.float32)
+    a[:8] = [0.0, 1.0, 4.0, 2.0, np.float32(1e-45), np.float32(1.1754944e-38), np.inf, np.float32(3.4e38)]
+    b = (np.exp(rng.uniform(np.log(1e-8), np.log(1e6), n)) ).astype(np.float32)
+    signed = a * np.where(rng.random(n) < 0.5, -1.0, 1.0).astype(np.float32)
+    bc = np.float32(np.sqrt(1.0 - 0.999 ** 37))
+    out = torch.empty(3 * n, dtype=torch.float32, device=DEV)
+
+    def run(x):
+        xa, xb = torch.as_tensor(x, device=DEV), torch.as_tensor(b, device=DEV)
+        assert lib.tg_debug_adam_math(xa.data_ptr(), xb.data_ptr(), ct.c_float(float(bc)), out.data_ptr(), n, None) == 0, lib.tg_last_error()
+        torch.cuda.synchronize()
+        return out.cpu().numpy().reshape(3, n)
+
+    r = run(a)
+    normal = (a >= np.float32(1.1754944e-38)) & np.isfinite(a)
+    with np.errstate(all="ignore"):
+        ref_sqrt = np.sqrt(a)                                   # IEEE, correctly rounded
+    assert np.array_equal(r[0][normal], ref_sqrt[normal]), int((r[0][normal] != ref_sqrt[normal]).sum())
+    assert r[0][0] == 0.0 and r[0][4] == a[4] and np.isinf(r[0][6])      # zero / denormal / inf pass through
+    ref_by = (a.astype(np.float32) / bc).astype(np.float32)
+    fin = np.isfinite(ref_by) & normal
+    assert np.array_equal(r[2][fin], ref_by[fin]), int((r[2][fin] != ref_by[fin]).sum())
+    r2 = run(signed)
+    with np.errstate(all="ignore"):
+        ref_div = (signed / b).astype(np.float32)
+    ok = np.isfinite(ref_div) & (np.abs(ref_div) >= np.float32(1.1754944e-38)) & normal
+    got, ref = r2[1][ok], ref_div[ok]
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, int(ulp.max())
+    assert (ulp != 0).mean() < 0.02, float((ulp != 0).mean())
+    print("tg_div_fr: fraction one ulp off the IEEE quotient %.2e" % float((ulp != 0).mean()))

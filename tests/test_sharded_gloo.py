@@ -300,3 +300,37 @@ def test_spatial_terms_on_two_shards_match_single_and_oracle(tmp_path):
     np.testing.assert_allclose(z0["hist"][:, _capi.H_TOTAL], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
     np.testing.assert_allclose(z0["total"], np.array(ho["total_loss"]), atol=2e-5, rtol=1e-5)
     assert np.abs(z0["P"] - Po).max() < 2e-5
+
+
+def test_peer_exchange_gives_up_on_a_missing_peer():
+    """The polls of the peer transport are bounded: an exchange whose peer never shows up ends after the time-out with the status word
+    raised (tg_comm_peer_status), and every later exchange returns at once instead of waiting again -- a lost rank costs one bounded
+    wait, never a hang.  (Emulated build, two communicators of one process, raw-pointer mailboxes; rank 1 simply never calls.)"""
+    import ctypes as ct
+    import time
+    sim_path = build_sim()
+    if sim_path is None:
+        pytest.skip("host clang not available to build the emulator")
+    from tangram_amd import _capi
+    lib = _capi._declare(ct.CDLL(sim_path))
+    comms, handles = [], ct.create_string_buffer(128)
+    for r in range(2):
+        c, h = ct.c_void_p(), ct.create_string_buffer(64)
+        assert lib.tg_comm_peer_create(2, r, 4096, 1, h, ct.byref(c)) == 0, lib.tg_last_error()
+        handles[64 * r: 64 * (r + 1)] = h.raw
+        comms.append(c)
+    for c in comms:
+        assert lib.tg_comm_peer_connect(c, handles) == 0, lib.tg_last_error()
+    assert lib.tg_comm_peer_set_timeout_ms(comms[0], 150.0) == 0
+    x = np.arange(3000, dtype=np.float32)
+    flag = ct.c_int(-1)
+    assert lib.tg_comm_peer_status(comms[0], ct.byref(flag)) == 0 and flag.value == 0
+    t0 = time.perf_counter()
+    assert lib.tg_comm_all_reduce_sum(comms[0], x.ctypes.data, x.size, None) == 0          # rank 1 never pushes
+    t1 = time.perf_counter()
+    assert 0.1 <= t1 - t0 < 5.0, t1 - t0
+    assert lib.tg_comm_peer_status(comms[0], ct.byref(flag)) == 0 and flag.value == 1
+    assert lib.tg_comm_all_reduce_sum(comms[0], x.ctypes.data, x.size, None) == 0          # ... and nobody waits a second time
+    assert time.perf_counter() - t1 < 0.1
+    for c in comms:
+        lib.tg_comm_destroy(c)
