@@ -31,6 +31,9 @@
 // `flag ? nontemporal_load : load` makes hipcc issue BOTH loads and select): non-temporal, so that 8.4 GB per iteration do
 // not churn L2 / MALL (-9 % on the update kernel at 30k x 10k); problems whose four arrays fit the 256 MB MALL keep ordinary
 // accesses and find M still cached in the next forward pass (+5 % there, profiles/r01 run34).
+#ifndef TG_X_TEMPORAL
+#define TG_X_TEMPORAL 0       // experiment switch (scripts/build_variant.sh -DTG_X_TEMPORAL=1): the backward product X stored and re-read with
+#endif                        // ordinary instead of non-temporal accesses, so that the update may find its tail in the Infinity Cache (review r04, item 6)
 template <bool STREAM, class T> TG_DEV T tg_ld_stream(const T* p) {
     if constexpr (STREAM) return __builtin_nontemporal_load(p); else return *p;
 }
@@ -1035,9 +1038,9 @@ TG_DEV void tg_bwd_body(const TgBwdArgs& a) {
             const f32x4 x = stg[row * RC + (j ^ (row & 15))];
             if (ok) {
                 if constexpr (PR::X16)
-                    tg_st_stream<STREAM>(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
+                    tg_st_stream<STREAM && !TG_X_TEMPORAL>(u32x2{tg_pack_bf16(x[0], x[1]), tg_pack_bf16(x[2], x[3])}, (u32x2*)((unsigned short*)a.X + (size_t)c * a.Vp + v));
                 else
-                    tg_st_stream<STREAM>(x, (f32x4*)((float*)a.X + (size_t)c * a.Vp + v));
+                    tg_st_stream<STREAM && !TG_X_TEMPORAL>(x, (f32x4*)((float*)a.X + (size_t)c * a.Vp + v));
             }
             if constexpr (ROWDOT) {
                 float pacc[NP];
@@ -1926,8 +1929,8 @@ TG_DEV void tg_adam_rowpass_body(const TgUpdateArgs& a) {
         const int v = 4 * (t + NT * q);
         const int vl = v < a.V ? v : 0;
         mq[q] = tg_ld_stream<STREAM>((const f32x4*)(a.M + row + vl));      // streamed once: non-temporal (see tg_adam_update)
-        if constexpr (X16) xr[q] = tg_ld_stream<STREAM>((const u32x2*)((const unsigned short*)a.X + row + vl));
-        else xr[q] = tg_ld_stream<STREAM>((const f32x4*)((const float*)a.X + row + vl));
+        if constexpr (X16) xr[q] = tg_ld_stream<STREAM && !TG_X_TEMPORAL>((const u32x2*)((const unsigned short*)a.X + row + vl));
+        else xr[q] = tg_ld_stream<STREAM && !TG_X_TEMPORAL>((const f32x4*)((const float*)a.X + row + vl));
     }
     // the moments travel while pass 1 computes -- except that the variants at the 128-register limit (4 waves per SIMD,
     // NT * NQ = 2560) request the second moment only behind the pass-1 sums, under the block reduction
