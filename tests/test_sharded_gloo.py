@@ -334,3 +334,36 @@ def test_peer_exchange_gives_up_on_a_missing_peer():
     assert time.perf_counter() - t1 < 0.1
     for c in comms:
         lib.tg_comm_destroy(c)
+
+
+def test_three_shards_over_the_peer_transport(tmp_path):
+    """world = 3 over the peer transport (three processes, shared-memory mailboxes): the rank-order sum of three vectors is not
+    commutative-safe like a sum of two, so this is the case that shows every rank adds in the SAME order -- all three ranks must hold
+    bit-identical histories, mappings, filters and projections -- and the run still is the single-engine run within tolerance."""
+    sim_path = build_sim()
+    if sim_path is None:
+        pytest.skip("host clang not available to build the emulator")
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, sim_path, str(tmp_path), "peer"), nprocs=3, join=True)
+    z = [np.load(tmp_path / f"sharded_{r}.npz") for r in range(3)]
+    for k in z[0].files:
+        np.testing.assert_array_equal(z[0][k], z[1][k], err_msg=k)
+        np.testing.assert_array_equal(z[0][k], z[2][k], err_msg=k)
+    from tangram_amd import _capi
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    _capi._install_library_for_tests(sim_path)
+    try:
+        C, K, V = 90, 30, 150
+        data = orc.make_synthetic(C, K, V, seed=21)
+        M0 = orc.reference_init_M(C, V, 5)
+        lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_r=1e-3)
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=lam)
+        h1 = e.new_history(4)
+        e.step(4, 0.1, h1)
+        P1 = e.result().numpy()
+    finally:
+        _capi._install_library_for_tests(None)
+    cols = [_capi.H_TOTAL, _capi.H_MAIN, _capi.H_VG, _capi.H_KL, _capi.H_ENTROPY]
+    np.testing.assert_allclose(z[0]["hist"][:, cols], h1.numpy()[:, cols], atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(z[0]["P"], P1, atol=1e-6)
