@@ -27,10 +27,14 @@ TOL = {
 #     largest multiple     libm    towards 0    away    hashed        MI355X (v_exp_f32 / v_log_f32)
 #     clusters kernels     1.44      2.49       2.12     1.60          3.0   (round 3, profiles/r03)
 #     GEMM kernels         2.22      1.72       2.74     2.00          2.2
-# i.e. anywhere in 1.4 - 2.7 for either family from a 1-ulp change of three scalar functions; the hardware's 3.0 is one more draw
-# from that distribution.  4 = 1.5 x the largest emulated draw.  (Round 3 carried two constants, 4 for the clusters kernels and 3
-# for the GEMM kernels: a bound fitted per family to one draw each.)
-OWN_SPREAD = 4.0
+# i.e. anywhere in 1.4 - 2.7 for either family from a 1-ulp change of three scalar functions; the hardware's 3.0 was one more draw
+# from that distribution (round 4 therefore carried 4 = 1.5 x the largest emulated draw).
+# Round 5 records what a GPU session measures (MEASURED_SPREAD below -> gpurun_out/own_spread_measured.json; committed copy:
+# profiles/r05/final/own_spread_measured.json): with this round's kernels the largest multiples on MI355X are 1.47 (clusters-mode
+# kernels, fp32 and bf16x3), 1.80 / 1.37 (GEMM kernels, bf16x3 / fp32) and 2.31 (GEMM kernels, plain bf16, against its own 100 x
+# wider tolerance).  The kernels are bit-reproducible (no atomics), so these are properties of the build, not of a box: the bound
+# goes back to 3 = 1.3 x the largest measured multiple (the round-4 advisor's request), one constant for both families.
+OWN_SPREAD = 3.0
 # every (case, term) whose whole-run check was decided by the drift bound leaves its measured multiple here; tests/conftest.py writes the
 # list to gpurun_out/own_spread_measured.json at the end of a GPU session (round-4 advisor: record the multiples a round measures)
 MEASURED_SPREAD = []
