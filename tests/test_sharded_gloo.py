@@ -243,7 +243,7 @@ def _spatial_problem():
     return data, M0, dict(voxel_weights=W, neighborhood_filter=N, ct_encode=data["ct_encode"], spatial_weights=Ws)
 
 
-def _spatial_worker(rank, world, port, sim_path, outdir):
+def _spatial_worker(rank, world, port, sim_path, outdir, transport="callbacks"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -253,11 +253,12 @@ def _spatial_worker(rank, world, port, sim_path, outdir):
         from tangram_amd.sharded import make_sharded
         import tangram_amd.mapping_optimizer as mo
         data, M0, graphs = _spatial_problem()
-        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=SP_LAM, **graphs)
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cpu", precision="fp32", lambdas=SP_LAM, transport=transport, **graphs)
         n = 4
         hist = sh.eng.new_history(n)
         sh.run(n, 0.1, hist)
         P = sh.result_full()
+        sh.peer_check()
         # the same through the Mapper seam (distributed=True): history keys of the reference + the mapping
         m = mo.Mapper(S=data["S"], G=data["G"], d=data["d"], device="cpu", gemm_precision="fp32", M_init=M0, distributed=True,
                       **{k: v for k, v in SP_LAM.items()}, **graphs)
@@ -268,13 +269,15 @@ def _spatial_worker(rank, world, port, sim_path, outdir):
         dist.destroy_process_group()
 
 
-def test_spatial_terms_on_two_shards_match_single_and_oracle(tmp_path):
+@pytest.mark.parametrize("transport", ["callbacks", "peer"])
+def test_spatial_terms_on_two_shards_match_single_and_oracle(tmp_path, transport):
     """Neighbourhood, cell-type-island and the three autocorrelation terms on 2 spot shards (mapping_optimizer.py:234-263 on the
-    whole spot graph: every rank gathers Ghat): same history and mapping as the unsharded engine and the fp64 oracle."""
+    whole spot graph: every rank gathers Ghat): same history and mapping as the unsharded engine and the fp64 oracle.
+    "peer": the gathered Ghat blocks are longer than the mailbox, i.e. this is the case that moves a vector in PIECES."""
     sim_path = build_sim()
     if sim_path is None:
         pytest.skip("host clang not available to build the emulator")
-    mp.spawn(_spatial_worker, args=(2, _free_port(), sim_path, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_spatial_worker, args=(2, _free_port(), sim_path, str(tmp_path), transport), nprocs=2, join=True)
     z0, z1 = np.load(tmp_path / "spatial_0.npz"), np.load(tmp_path / "spatial_1.npz")
     for k in z0.files:
         np.testing.assert_array_equal(z0[k], z1[k], err_msg=k)
