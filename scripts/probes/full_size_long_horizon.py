@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=50)
     ap.add_argument("--shape", default="30000,1000,10000")
     ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--constrained", action="store_true", help="MapperConstrained (BASELINE config 5a) instead of Mapper")
     args = ap.parse_args()
     from oracle import make_ref
     from oracle import tangram_oracle as orc
@@ -41,14 +42,27 @@ def main():
     data = orc.make_synthetic(C, K, V, seed=2)
     lam = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
     t0 = time.perf_counter()
-    m = ref_mo.Mapper(S=data["S"], G=data["G"], d=data["d"], device="cpu", random_state=42, **lam)
-    M0 = m.M.detach().numpy().copy()
-    t1 = time.perf_counter()
-    P_ref, hist = m.train(num_epochs=n, learning_rate=0.1, print_each=None)
+    if args.constrained:
+        lam.update(lambda_count=1.0, lambda_f_reg=1.0)
+        tc = float(V // 2)
+        m = ref_mo.MapperConstrained(S=data["S"], G=data["G"], d=data["d"], device="cpu", random_state=42, target_count=tc, **lam)
+        M0, F0 = m.M.detach().numpy().copy(), m.F.detach().numpy().copy()
+        t1 = time.perf_counter()
+        P_ref, F_ref, hist = m.train(num_epochs=n, learning_rate=0.1, print_each=None)
+        ref = {}                               # (stringified with 4 decimals, mapping_optimizer.py:630: the state carries the precision)
+    else:
+        m = ref_mo.Mapper(S=data["S"], G=data["G"], d=data["d"], device="cpu", random_state=42, **lam)
+        M0 = m.M.detach().numpy().copy()
+        t1 = time.perf_counter()
+        P_ref, hist = m.train(num_epochs=n, learning_rate=0.1, print_each=None)
+        ref = {k: np.array([float(x) for x in v], dtype=np.float64) for k, v in hist.items() if len(v)}
     t2 = time.perf_counter()
     M_ref = m.M.detach().numpy()
-    ref = {k: np.array([float(x) for x in v], dtype=np.float64) for k, v in hist.items() if len(v)}
-    e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision="bf16x3", lambdas=lam)
+    if args.constrained:
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], F0=F0, mode="constrained", device="cuda:0", precision="bf16x3", lambdas=lam,
+                            target_count=tc)
+    else:
+        e = HipMapperEngine(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision="bf16x3", lambdas=lam)
     h = e.new_history(n)
     e.step(n, 0.1, h)
     torch.cuda.synchronize()
@@ -58,14 +72,18 @@ def main():
     by_epoch = {str(ep): {k: float(abs(hh[ep - 1, j] - ref[k][ep - 1])) for k, j in cols.items() if k in ref}
                 for ep in sorted(set([1, 2, 4, 8] + list(range(10, n + 1, 10)) + [n])) if ep <= n}
     dM = np.abs(e.logits()[0][:, :V].cpu().numpy() - M_ref)
-    P = e.result().cpu().numpy()
+    res = e.result(with_filter=args.constrained)
+    P = (res[0] if args.constrained else res).cpu().numpy()
+    S_eff = data["S"] * np.asarray(F_ref)[:, None] if args.constrained else data["S"]
     with torch.no_grad():
-        proj_ref = (torch.from_numpy(P_ref).T @ torch.from_numpy(np.ascontiguousarray(data["S"]))).numpy()
+        proj_ref = (torch.from_numpy(P_ref).T @ torch.from_numpy(np.ascontiguousarray(S_eff.astype(np.float32)))).numpy()
     proj = e.project().cpu().numpy()
     out = dict(probe="full_size_long_horizon", shape=[C, K, V], epochs=n, precision="bf16x3", terms=lam,
                reference_s_per_epoch=(t2 - t1) / n, reference_init_s=t1 - t0, host_threads=args.threads,
                max_abs_loss_difference_over_all_epochs=per_term, loss_difference_by_epoch=by_epoch,
-               final_main_loss=dict(reference=float(ref["main_loss"][-1]), library=float(hh[-1, _capi.H_MAIN])),
+               final_main_loss=dict(reference=float(ref["main_loss"][-1]) if ref else None, library=float(hh[-1, _capi.H_MAIN])),
+               mapper="MapperConstrained" if args.constrained else "Mapper",
+               filter_max_abs_difference=float(np.abs(res[1].cpu().numpy() - np.asarray(F_ref)).max()) if args.constrained else None,
                logits=dict(max_dM=float(dM.max()), frac_beyond_1e_3=float((dM > 1e-3).mean()), frac_beyond_1e_4=float((dM > 1e-4).mean()),
                            rms_dM=float(np.sqrt((dM.astype(np.float64) ** 2).mean()))),
                mapping_rel_fro=float(np.linalg.norm((P - P_ref).astype(np.float64)) / np.linalg.norm(P_ref.astype(np.float64))),
