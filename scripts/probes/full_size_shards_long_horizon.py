@@ -81,7 +81,7 @@ def main():
         mp.spawn(worker, args=(world, port, tmp, n, m0_path), nprocs=world, join=True)
         t_sh = time.perf_counter() - t0
         z = [np.load(os.path.join(tmp, f"rank_{r}.npz")) for r in range(world)]
-        same_hist = all(np.array_equal(z[r]["hist"], z[0]["hist"]) for r in range(1, world))
+        same_hist = all(np.array_equal(z[r]["hist"], z[0]["hist"], equal_nan=True) for r in range(1, world))      # (disabled terms are NaN, like the reference)
         hh = z[0]["hist"].astype(np.float64)
         M = np.concatenate([z[r]["M"] for r in range(world)], axis=1)
         P = np.concatenate([z[r]["P"] for r in range(world)], axis=1)
