@@ -1099,8 +1099,15 @@ struct TgSpmmArgs {
 };
 // (4 genes per thread: float4 loads of the gathered rows -- a quarter of the load instructions of the one-gene-per-thread
 //  version, 16 bytes per lane; the last, partial quad of [k_begin, k_end) is guarded per element)
+// Round 5: (i) workgroup b runs on XCD b % 8, and the rows a spot gathers are its neighbours on the tissue, i.e. nearby rows: XCD x
+// takes a CONTIGUOUS band of spots (rows x * V/8 ...), so that a band's gathered rows are shared through that XCD's L2 instead of every
+// XCD streaming the whole matrix; (ii) the non-zeros of a row are taken eight at a time with every gathered row requested before the
+// first is used (the one-at-a-time loop was a chain of ~7 dependent row loads).  Same sums in the same order: same bits.
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_spmm(TgSpmmArgs a) {
-    const int v = blockIdx.x;
+    constexpr int U = 8;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    const int v = xcd * q + (xcd < r ? xcd : r) + j;            // (blocks with j == q exist for xcd < r only: every row exactly once)
     const int b = a.W.indptr[v], e = a.W.indptr[v + 1];
     for (int k = a.k_begin + 4 * threadIdx.x; k < a.k_end; k += 1024) {
         const size_t o = (size_t)v * a.Kp + k;
@@ -1108,13 +1115,25 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_spmm(TgSpmmArgs a) {
         const f32x4 xv = a.E ? *(const f32x4*)(a.A + o) : s;
         f32x4 ca = {1.f, 1.f, 1.f, 1.f}, cb = s;
         if (a.ca) { ca = *(const f32x4*)(a.ca + k); cb = *(const f32x4*)(a.cb + k); }
-        for (int i = b; i < e; ++i) {
-            const size_t off = (size_t)a.W.indices[i] * a.Kp + k;
-            const float w = a.W.data[i];
-            f32x4 x = *(const f32x4*)(a.A + off);
-            if (a.ca) { const f32x4 y = *(const f32x4*)(a.B + off); x = ca * x + cb * y; }
-            s += w * x;
-            if (a.E) { const f32x4 dx = x - xv; ge += w * dx * dx; }
+        for (int i0 = b; i0 < e; i0 += U) {
+            f32x4 x[U], y[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = i0 + u < e;
+                const size_t off = (size_t)(ok ? a.W.indices[i0 + u] : v) * a.Kp + k;        // (beyond the row: its own row, unused)
+                w[u] = ok ? a.W.data[i0 + u] : 0.f;
+                x[u] = *(const f32x4*)(a.A + off);
+                if (a.ca) y[u] = *(const f32x4*)(a.B + off);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u >= e) continue;
+                f32x4 xx = x[u];
+                if (a.ca) xx = ca * xx + cb * y[u];
+                s += w[u] * xx;
+                if (a.E) { const f32x4 dx = xx - xv; ge += w[u] * dx * dx; }
+            }
         }
         if (a.addD) s += *(const f32x4*)(a.addD + o);
         if (a.addc) s -= *(const f32x4*)(a.addc + k);
@@ -1122,9 +1141,9 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_spmm(TgSpmmArgs a) {
             if (a.E) *(f32x4*)(a.E + o) = ge;
             *(f32x4*)(a.Y + o) = a.accumulate ? *(const f32x4*)(a.Y + o) + s : s;
         } else {
-            for (int q = 0; q < 4 && k + q < a.k_end; ++q) {
-                if (a.E) a.E[o + q] = ge[q];
-                a.Y[o + q] = a.accumulate ? a.Y[o + q] + s[q] : s[q];
+            for (int qq = 0; qq < 4 && k + qq < a.k_end; ++qq) {
+                if (a.E) a.E[o + qq] = ge[qq];
+                a.Y[o + qq] = a.accumulate ? a.Y[o + qq] + s[qq] : s[qq];
             }
         }
     }
