@@ -1,0 +1,128 @@
+"""The peer-memory transport of the sharded step (tg_comm_peer_*) in its deployment form, as far as a 1-GPU box can
+show it: one PROCESS per rank, all sharing cuda:0, mailboxes crossing the process boundary as hipIpc handles; against the rank-order
+callback transport on the same shards (threads of this process).  This module sorts last among the GPU tests on purpose: its tests
+start 2 - 8 processes that wait for each other with bounded polls -- should a loaded box ever make one of them late, a `-x` run has
+every other GPU test behind it already."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+PEER_SHAPE = (2600, 300, 1300, 4)        # C, K, V, epochs of the peer-transport cases
+PEER_LAM = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5)
+PEER_LAM_C = dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5, lambda_count=1.0, lambda_f_reg=1.0)
+
+
+def _peer_problem(constrained, shape=None):
+    from oracle import tangram_oracle as orc
+    C, K, V, n = shape or PEER_SHAPE
+    data = orc.make_synthetic(C, K, V, seed=31)
+    if constrained:
+        M0, F0 = orc.reference_init_MF_constrained(C, V, 5)
+        return data, M0, dict(F0=F0, mode="constrained", target_count=float(V // 2)), PEER_LAM_C
+    return data, orc.reference_init_M(C, V, 5), {}, PEER_LAM
+
+
+def _peer_worker(rank, world, port, outdir, constrained, transport="peer", shape=None):
+    """One PROCESS per rank, all on cuda:0: the mailboxes cross the process boundary as hipIpc handles; gloo only bootstraps."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TG_PEER_TIMEOUT_MS"] = "30000"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tangram_amd.sharded import make_sharded
+        data, M0, kw, lam = _peer_problem(constrained, shape)
+        n = (shape or PEER_SHAPE)[3]
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device="cuda:0", precision="bf16x3", lambdas=lam, transport=transport, **kw)
+        assert sh.transport == "peer"           # ("peer_checked": the set-up's self-test against gloo's collectives passed)
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist, 0)
+        torch.cuda.synchronize()
+        sh.peer_check()
+        res = sh.result_local(with_filter=constrained)
+        np.savez(os.path.join(outdir, f"peer_{rank}.npz"), hist=hist.cpu().numpy(), M=sh.eng.logits()[0][:, : sh.eng.V].cpu().numpy(),
+                 P=res[0].cpu().numpy())
+        sh.release()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,constrained,transport", [(2, False, "peer"), (3, False, "peer"), (4, False, "peer"), (2, True, "peer"),
+                                                         (2, False, "peer_checked")])
+def test_peer_transport_over_hip_ipc_equals_the_callback_transport(tmp_path, world, constrained, transport):
+    """The third transport (tg_comm_peer_*: ONE exchange kernel per rank -- write-through stores into every rank's mailbox, flag, wait
+    for the peers' flags, sum in rank order) in its deployment form, as far as a 1-GPU box can show it: `world` PROCESSES share
+    cuda:0, map each other's mailboxes through hipIpcGetMemHandle / hipIpcOpenMemHandle and step the sharded C schedule.  Reference:
+    the callback transport on the same shards (threads of THIS process, tests/local_comm.py), which also sums the ranks' vectors in
+    rank order -- so history, logits and mapping must agree BIT FOR BIT, and the global history is the same on every rank.
+    "peer_checked" = what `transport="auto"` does on an nccl group of one node: set-up + a self-test against the process group's own
+    collectives (gloo here), all ranks agreeing on the verdict, before the transport is trusted with the run.
+    (Ranks as threads of one process cannot test the peer kernels reliably: a rank's exchange kernel waits for its peers' kernels, and
+    two streams of one process may share a hardware queue -- measured: the first such case timed out, profiles/r05/run2_peer.)"""
+    import socket
+    import torch.multiprocessing as mp
+    from tangram_amd.sharded import make_sharded
+    from tests.local_comm import run_ranks
+    data, M0, kw, lam = _peer_problem(constrained)
+    n = PEER_SHAPE[3]
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, comm=comm, transport="callbacks", **kw)
+        hist = sh.eng.new_history(n)
+        sh.run(n, 0.1, hist, 0)
+        out = dict(hist=hist.cpu().numpy(), M=sh.eng.logits()[0][:, : sh.eng.V].cpu().numpy(), P=sh.result_local(with_filter=constrained)[0].cpu().numpy())
+        sh.release()
+        return out
+
+    ref = run_ranks(world, rank_fn)
+    torch.cuda.synchronize()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_peer_worker, args=(world, port, str(tmp_path), constrained, transport), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"peer_{r}.npz")
+        for k in ("hist", "M", "P"):
+            np.testing.assert_array_equal(z[k], ref[r][k], err_msg=f"rank {r}: {k}")
+        np.testing.assert_array_equal(z["hist"], ref[0]["hist"])          # the global history, identical on every rank
+
+
+def test_peer_transport_eight_processes_at_the_full_cfg3_shape(tmp_path):
+    """BASELINE config 3 as it is deployed -- 30 000 x 1 000 x 10 000, EIGHT ranks of 1 250 spots, one process per rank, the peer
+    transport -- with the one substitution a 1-GPU box forces: the eight processes share cuda:0 instead of owning a GPU each (their
+    mailboxes still cross process boundaries as hipIpc handles, their exchange kernels still wait for each other).  Against the
+    rank-order callback transport on the same eight shards (threads of this process): history, logits and mapping bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from tangram_amd.sharded import make_sharded
+    from tests.local_comm import run_ranks
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * (1 << 30):
+        pytest.skip("needs ~40 GB of free HBM")
+    shape, world = (30000, 1000, 10000, 3), 8
+    data, M0, kw, lam = _peer_problem(False, shape)
+
+    def rank_fn(comm):
+        sh = make_sharded(data["S"], data["G"], M0, d=data["d"], device=DEV, precision="bf16x3", lambdas=lam, comm=comm, transport="callbacks")
+        hist = sh.eng.new_history(shape[3])
+        sh.run(shape[3], 0.1, hist, 0)
+        out = dict(hist=hist.cpu().numpy(), M=sh.eng.logits()[0][:, : sh.eng.V].cpu().numpy(), P=sh.result_local()[0].cpu().numpy())
+        sh.release()
+        return out
+
+    ref = run_ranks(world, rank_fn)
+    torch.cuda.synchronize()
+    del data, M0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_peer_worker, args=(world, port, str(tmp_path), False, "peer", shape), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"peer_{r}.npz")
+        for k in ("hist", "M", "P"):
+            np.testing.assert_array_equal(z[k], ref[r][k], err_msg=f"rank {r}: {k}")
+        np.testing.assert_array_equal(z["hist"], ref[0]["hist"])
