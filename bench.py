@@ -100,7 +100,7 @@ def csrc_sha():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tangram_amd", "csrc")
-    for name in ("tg_device.h", "tg_kernels.h", "tg_capi.hip"):
+    for name in sorted(n for n in os.listdir(d) if n.startswith("tg_") and n.endswith((".h", ".hip"))):     # every header of the split kernel sources
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 

@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "tg_capi.hip")
 OUT = os.path.join(CSRC, "libtangram_hip.so")
-DEPS = [SRC, os.path.join(CSRC, "tg_kernels.h"), os.path.join(CSRC, "tg_device.h"),
-        os.path.join(os.path.dirname(HERE), "include", "tangram_hip.h")]
+HEADERS = ("tg_device.h", "tg_kernels.h", "tg_peer.h", "tg_gemm.h", "tg_stats.h", "tg_spatial.h", "tg_small.h", "tg_update.h", "tg_setup.h")
+DEPS = [SRC] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "tangram_hip.h")]
 
 
 def _stale(out, deps):

@@ -7,9 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(ROOT, "tangram_amd", "csrc", "tg_capi.hip")
 OUT = os.path.join(HERE, "libtangram_sim.so")
-DEPS = [SRC, os.path.join(ROOT, "tangram_amd", "csrc", "tg_kernels.h"),
-        os.path.join(ROOT, "tangram_amd", "csrc", "tg_device.h"), os.path.join(HERE, "hipsim.h"),
-        os.path.join(ROOT, "include", "tangram_hip.h")]
+import glob
+DEPS = [SRC] + sorted(glob.glob(os.path.join(ROOT, "tangram_amd", "csrc", "tg_*.h"))) + [os.path.join(HERE, "hipsim.h"),
+                                                                                       os.path.join(ROOT, "include", "tangram_hip.h")]
 
 
 def host_clang():
