@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 5
+#define TG_ABI_VERSION 6
 
 typedef enum tg_status {
     TG_OK = 0,
@@ -98,6 +98,8 @@ typedef struct tg_sizes {
     size_t workspace_bytes;  /* operand images of S, G copy, partial sums, coefficient vectors */
     int32_t m_pitch;         /* row pitch of M in floats (n_spots rounded up to 64) */
     int32_t history_terms;   /* floats per history row */
+    size_t peer_step_floats; /* spot shards (n_ranks >= 1), ABI version 6: granules per (slot, rank) of the STEP AREA a peer communicator needs for
+                                this handle to run its three per-step exchanges inside its kernels (tg_comm_peer_create_stepped); 0 = not applicable */
 } tg_sizes;
 
 /* Inputs of the constructor (mapping_optimizer.py:83-157): caller-owned device arrays, fp32 row-major. */
@@ -161,6 +163,16 @@ int tg_comm_create_rccl(const char* librccl_path, const void* id128, int world, 
  * an exchange is a launch argument).  A poll that does not meet its peers within TG_PEER_TIMEOUT_MS (environment, default 20 000)
  * gives up and sets a flag that tg_comm_peer_status reports: a lost peer costs a bounded wait, never a hang. */
 int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out);
+/* ABI version 6: the same with a STEP AREA behind the generic one.  step_floats = tg_sizes.peer_step_floats of the handle that will be
+ * attached (0: none, = tg_comm_peer_create).  With it tg_mapper_step no longer launches an exchange kernel between its kernels: the
+ * per-gene statistics are pushed and polled inside tg_gene_reduce; the update kernel sums the backward GEMM's row-dot partials of its
+ * row itself, pushes them, polls the peers' and goes on (its first loads already in flight); the row pairs are pushed from the update
+ * kernel's tail and polled at the head of tg_merge_stats: 7 launches per step instead of 11, every sum in the same order as on the other
+ * transports (bit-identical results).  Runs with spatial terms keep the exchange kernels.  colocated: how many ranks of this communicator
+ * run on THIS rank's device (1 in deployment; the one-GPU tests pass the world size: kernels that wait for their peers then leave room
+ * for the peers' kernels). */
+int tg_comm_peer_create_stepped(int world, int rank, size_t capacity_floats, size_t step_floats, int colocated, int same_process,
+                         void* handle64_out, tg_comm** out);
 int tg_comm_peer_connect(tg_comm* c, const void* handles_world_x_64);
 int tg_comm_peer_status(tg_comm* c, int* timed_out);
 int tg_comm_peer_set_timeout_ms(tg_comm* c, double ms);      /* bound of the polls of the exchanges issued from now on */

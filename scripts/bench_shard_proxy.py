@@ -23,9 +23,20 @@ def main():
     out = {}
     # (transport "peer": the library's own one-hop exchange kernels; on ONE rank they push to and read from the rank's own mailbox,
     #  i.e. the kernel's fixed cost without a link -- as the 1-rank RCCL collectives show RCCL's enqueue + local copy)
-    for (C, K, V, parts, prec, transport) in ((30000, 1000, 10000, 8, "bf16x3", "rccl"), (30000, 1000, 10000, 8, "bf16x3", "peer"),
-                                              (30000, 1000, 10000, 4, "bf16x3", "rccl"), (30000, 1000, 10000, 2, "bf16x3", "rccl"),
-                                              (30000, 1000, 10000, 8, "bf16", "rccl"), (30000, 1000, 10000, 8, "bf16", "peer")):
+    # "peer": the exchanges inside the kernels (round 6; "+persist": the row kernel as a persistent grid); "peer_kernels": round 5's form,
+    # one exchange kernel between the library's kernels (TG_PEER_FUSED=0)
+    cases = ((30000, 1000, 10000, 8, "bf16x3", "rccl"), (30000, 1000, 10000, 8, "bf16x3", "peer"), (30000, 1000, 10000, 8, "bf16x3", "peer+persist"),
+             (30000, 1000, 10000, 8, "bf16x3", "peer_kernels"),
+             (30000, 1000, 10000, 4, "bf16x3", "rccl"), (30000, 1000, 10000, 4, "bf16x3", "peer"),
+             (30000, 1000, 10000, 2, "bf16x3", "rccl"), (30000, 1000, 10000, 2, "bf16x3", "peer"),
+             (30000, 1000, 10000, 8, "bf16", "rccl"), (30000, 1000, 10000, 8, "bf16", "peer"))
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    for (C, K, V, parts, prec, tname) in cases:
+        if only and not any(o in f"{parts}_{prec}_{tname}" for o in only):
+            continue
+        transport = "peer" if tname.startswith("peer") else tname
+        os.environ["TG_PEER_FUSED"] = "0" if tname == "peer_kernels" else "1"
+        os.environ["TG_ROWPASS_PERSIST"] = "1" if tname.endswith("+persist") else "0"
         Vl = V // parts
         w = make_workload(C, K, V, dev, seed=0)
         M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous()
@@ -46,7 +57,7 @@ def main():
         kern = {name: round(1e3 * ms / max(cnt, 1), 1) for name, ms, cnt in e.eng.profile_read()}
         e.eng.profile(False)
         e.peer_check()
-        out[f"{C}x{K}x{Vl}_of_{parts}_{prec}_{transport}"] = dict(ms_per_step=1e3 * t_all / n, host_enqueue_ms_per_step=1e3 * t_enq / n,
+        out[f"{C}x{K}x{Vl}_of_{parts}_{prec}_{tname}"] = dict(ms_per_step=1e3 * t_all / n, host_enqueue_ms_per_step=1e3 * t_enq / n,
                                                       main_loss=float(hist[-1, 1]), kernels_us=kern)
         del e, w, M0
     print(json.dumps(out))

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtangram_hip.so")      # the in-tree build, nothing else (experiments: scripts/with_lib.py)
 
-TG_ABI_VERSION = 5
+TG_ABI_VERSION = 6
 TG_MODE_MAPPER, TG_MODE_CONSTRAINED = 0, 1
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 H_NTERMS = 16
@@ -39,7 +39,7 @@ ALL_GATHER_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct
 
 class TgSizes(ct.Structure):
     _fields_ = [("state_bytes", ct.c_size_t), ("workspace_bytes", ct.c_size_t),
-                ("m_pitch", ct.c_int32), ("history_terms", ct.c_int32)]
+                ("m_pitch", ct.c_int32), ("history_terms", ct.c_int32), ("peer_step_floats", ct.c_size_t)]
 
 
 class TgInputs(ct.Structure):
@@ -66,12 +66,13 @@ def _declare(lib):
     lib.tg_comm_rccl_unique_id.argtypes = [ct.c_char_p, vp]
     lib.tg_comm_create_rccl.argtypes = [ct.c_char_p, vp, i32, i32, ct.POINTER(vp)]
     lib.tg_comm_peer_create.argtypes = [i32, i32, ct.c_size_t, i32, vp, ct.POINTER(vp)]
+    lib.tg_comm_peer_create_stepped.argtypes = [i32, i32, ct.c_size_t, ct.c_size_t, i32, i32, vp, ct.POINTER(vp)]
     lib.tg_comm_peer_connect.argtypes = [vp, vp]
     lib.tg_comm_peer_status.argtypes = [vp, ct.POINTER(i32)]
     lib.tg_comm_peer_set_timeout_ms.argtypes = [vp, ct.c_double]
     lib.tg_comm_all_reduce_sum.argtypes = [vp, vp, ct.c_size_t, vp]
     lib.tg_comm_all_gather.argtypes = [vp, vp, vp, ct.c_size_t, vp]
-    for name in ("tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_peer_set_timeout_ms", "tg_comm_all_reduce_sum",
+    for name in ("tg_comm_peer_create", "tg_comm_peer_create_stepped", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_peer_set_timeout_ms", "tg_comm_all_reduce_sum",
                  "tg_comm_all_gather"):
         getattr(lib, name).restype = i32
     lib.tg_comm_destroy.argtypes = [vp]
@@ -115,7 +116,7 @@ def _declare(lib):
 
 
 EXPORTS = ["tg_abi_version", "tg_last_error", "tg_query_sizes", "tg_mapper_create", "tg_mapper_destroy",
-           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_peer_create", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_peer_set_timeout_ms",
+           "tg_mapper_step", "tg_comm_create_callbacks", "tg_comm_rccl_unique_id", "tg_comm_create_rccl", "tg_comm_peer_create", "tg_comm_peer_create_stepped", "tg_comm_peer_connect", "tg_comm_peer_status", "tg_comm_peer_set_timeout_ms",
            "tg_comm_all_reduce_sum", "tg_comm_all_gather", "tg_comm_destroy",
            "tg_mapper_attach_comm", "tg_mapper_result",
            "tg_mapper_project", "tg_mapper_project_genes", "tg_csr_columns_to_dense", "tg_csr_gather_columns", "tg_row_sums",

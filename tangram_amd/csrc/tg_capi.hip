@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -145,6 +146,8 @@ struct TgLayout {
     int fwd_units;                                    // workgroups the forward (tile, step) space is cut into (tg_kernels.h, tg_fwd_unit_*)
     int bwd_T;                                        // tile edge of the backward GEMM (T, or 128 under the 256 layout: tg_make_layout)
     size_t o_gathered, pair_stride;
+    size_t o_peertab;                                 // spot shards: every rank's mailbox as mapped here (TgPeerLink::box), 128 bytes
+    size_t step_e2, step_e3, step_e1, step_floats;    // spot shards: regions of the peer transport's step area (granules), tg_peer.h
     size_t s_M, s_m1, s_m2, s_F, s_total;
 };
 
@@ -281,6 +284,9 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
         const double rounds = (double)L->nct * (double)L->nvt / 256.0, frac = rounds - (double)(long)rounds;
         if (cfg->bwd_tile) L->bwd_T = cfg->bwd_tile;
         else if (rowdot && rounds < 4.0 && frac > 0.0 && frac < 0.4) L->bwd_T = 128;
+        // (Round 6 measured a SPLIT pass -- the cell tiles of the whole rounds on 256^2 tiles, the ragged band as a second launch on 128^2:
+        //  slower on every shard shape, 220 -> 277 / 395 -> 464 / 763 -> 795 us at 1/8, 1/4, 1/2 of cfg2: a round of 512 small tiles costs
+        //  0.7 of a 256^2 round however full it is, and the second kernel starts behind the first one's drain.  profiles/r06/run2.)
     }
     L->nrb = (L->Vr + TG_RB - 1) / TG_RB;
     L->Vs = L->sp_shard ? L->Vtot : L->V;
@@ -341,7 +347,14 @@ static int tg_make_layout(const tg_config* cfg_in, TgLayout* L) {
     L->pair_stride = (size_t)2 * L->C + TG_PAIR_TAIL;     // (max, sum exp) pairs + the per-rank history partials
     L->o_rowpair = take(L->pair_stride * 4);
     L->nranks = cfg->n_ranks > 1 ? cfg->n_ranks : 1;
-    if (cfg->n_ranks >= 1 || L->Vtot != L->V) L->o_gathered = take((size_t)L->nranks * L->pair_stride * 4);   // (n_ranks = 1: a 1-rank communicator)
+    if (cfg->n_ranks >= 1 || L->Vtot != L->V) {
+        L->o_gathered = take((size_t)L->nranks * L->pair_stride * 4);   // (n_ranks = 1: a 1-rank communicator)
+        L->o_peertab = take(256);
+        L->step_e2 = 0;
+        L->step_e3 = rup((size_t)2 * L->Kp, 64);
+        L->step_e1 = L->step_e3 + rup((size_t)TGP1_N * L->C, 64);
+        L->step_floats = L->step_e1 + rup(L->pair_stride, 64);
+    }
     L->o_scal = take(64 * 4);
     L->o_fsum = take(64 * 4);
     L->o_X = take((size_t)L->C * L->Vp * 4);
@@ -407,6 +420,7 @@ extern "C" int tg_query_sizes(const tg_config* cfg, tg_sizes* out) {
     out->workspace_bytes = L.total;
     out->m_pitch = L.Vp;
     out->history_terms = TG_H_NTERMS;
+    out->peer_step_floats = L.step_floats;
     return TG_OK;
 }
 
@@ -425,6 +439,7 @@ struct tg_mapper {
     bool fin_pending;
     TgFinalizeArgs fin_args;
     tg_comm* comm;                                   // spot-sharded run: the communicator (borrowed), else null
+    bool fused;                                      // ... whose exchanges happen inside the kernels (peer transport with a step area)
     // profiling
     bool prof;
     std::vector<std::string> prof_names;
@@ -760,7 +775,7 @@ extern "C" int tg_mapper_create(const tg_config* cfg, const tg_inputs* in, void*
     cfg = &m->cfg;
     m->ws = (unsigned char*)workspace_dev; m->st = (unsigned char*)state_dev;
     m->stream = (tg_stream_t)hip_stream;
-    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->comm = nullptr;
+    m->step = 0; m->ready = false; m->prof = false; m->fin_pending = false; m->comm = nullptr; m->fused = false;
     // M, Adam m, v (fp32) and X (fp32 or bf16) of this handle against the 256 MB MALL, with room left for the GEMM operands
     m->stream_once = (size_t)L.C * L.Vp * (12 + (cfg->precision == TG_PREC_BF16 ? 2 : 4)) > ((size_t)192 << 20);
     m->s_adam = nullptr; m->s_fwd = nullptr;
@@ -897,13 +912,17 @@ static TgGhatReduceArgs tg_ghat_args(tg_mapper* m, bool force_vox) {
     return a;
 }
 
-static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false) {
+struct TgPeerLink;
+static int tg_launch_ghat_stats(tg_mapper* m, bool force_vox = false, const TgPeerLink* link = nullptr) {
     const TgLayout& L = m->L;
     const TgGhatReduceArgs a = tg_ghat_args(m, force_vox);
     const int nrb = (L.V + TG_RB - 1) / TG_RB;
     TG_LAUNCH(tg_ghat_reduce, nrb, (L.Kp + TG_GH_COLS - 1) / TG_GH_COLS, 256, 4 * 64 * 2 * 16, m->stream, a);
     tg_prof_mark(m, "tg_ghat_reduce");
-    if (nrb > 512) {              // many row blocks, e.g. clusters mode on 50 000 spots: 16 genes x 64 groups per workgroup
+    if (link) {                   // spot shard, peer transport: the exchange of the statistics happens inside this kernel
+        if (nrb > 512) TG_LAUNCH(tg_gene_reduce_tall_x, (L.Kp + 15) / 16, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp, m->fp(L.o_genestat), *link);
+        else TG_LAUNCH(tg_gene_reduce_x, (L.Kp + 63) / 64, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp, m->fp(L.o_genestat), *link);
+    } else if (nrb > 512) {       // many row blocks, e.g. clusters mode on 50 000 spots: 16 genes x 64 groups per workgroup
         TG_LAUNCH(tg_gene_reduce_tall, (L.Kp + 15) / 16, 1, 1024, TG_GR_GROUPS * 64 * 2 * 4, m->stream, (const float*)m->fp(L.o_genepart), nrb, L.Kp,
                   m->fp(L.o_genestat));
     } else {
@@ -1000,16 +1019,17 @@ static TgBwdArgs tg_bwd_args(tg_mapper* m, int ct0, int ct1, int* grid_out, int 
 }
 
 template <class PR>
-static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bool x_only = false) {
+static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bool x_only = false, int tile = 0) {
     const TgLayout& L = m->L;
     int grid;
     // (the cached-access variant exists for the single-GPU X-only epilogue only: the row-dot variants serve spot shards and
     //  very long rows, i.e. big problems, and every GEMM instantiation costs seconds of compile time)
     // ct0, ct1 count tiles of L.T cells; under the 256 layout the kernel may run on 128^2 tiles (L.bwd_T, see tg_make_layout)
-    const int f = L.T / L.bwd_T;
-    const TgBwdArgs a = tg_bwd_args<PR>(m, f * ct0, f * ct1, &grid, L.bwd_T);
+    if (tile == 0) tile = L.bwd_T;
+    const int f = L.T / tile;
+    const TgBwdArgs a = tg_bwd_args<PR>(m, f * ct0, f * ct1, &grid, tile);
 #define TG_BWD_GO(GE, F, R, S) TG_LAUNCH((tg_bwd_kernel<PR, GE, F, R, S>), grid, 1, GE::NT, GE::BWD_LDS_BYTES, stream, a)
-    if (L.bwd_T == 256) {
+    if (tile == 256) {
         if (x_only) { if (m->stream_once) TG_BWD_GO(TgGeoLarge, false, false, true); else TG_BWD_GO(TgGeoLarge, false, false, false); }
         else if (L.full) TG_BWD_GO(TgGeoLarge, true, true, true);
         else TG_BWD_GO(TgGeoLarge, false, true, true);
@@ -1021,12 +1041,17 @@ static void tg_launch_bwd(tg_mapper* m, tg_stream_t stream, int ct0, int ct1, bo
 #undef TG_BWD_GO
 }
 
-static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1) {
+static int tg_polling_grid(tg_mapper* m, const void* fn, int nt, int lds, int want);      // (spot-sharded section below)
+static bool tg_grid_strided(const tg_mapper* m);
+static void tg_launch_rowsum(tg_mapper* m, tg_stream_t stream, int c0, int c1, const TgPeerLink* link = nullptr) {
     const TgLayout& L = m->L;
     TgRowsumArgs r;
     r.part = m->fp(L.o_part); r.nvt = L.Vr / L.bwd_T; r.C = L.C; r.rowq = m->fp(L.o_rowq); r.np = L.full ? TGP1_N : 1;
     r.c_begin = c0; r.c_end = c1;
-    TG_LAUNCH(tg_rowsum_parts, (c1 - c0 + 15) / 16, 1, 256, 16 * 16 * 4, stream, r);
+    r.xch = 0; r.link.world = 0;
+    int grid = (c1 - c0 + 15) / 16;
+    if (link) { r.xch = 1; r.link = *link; if (tg_grid_strided(m)) grid = tg_polling_grid(m, (const void*)tg_rowsum_parts, 256, 2048, grid); }
+    TG_LAUNCH(tg_rowsum_parts, grid, 1, 256, 2048, stream, r);
 }
 
 static void tg_launch_hist_regs(tg_mapper* m, tg_stream_t stream, float* hist_row) {
@@ -1057,6 +1082,7 @@ static TgUpdateArgs tg_update_args(tg_mapper* m, float lr, bool finalize, int c0
     u.bc2_sqrt = (float)sqrt(1.0 - pow((double)m->cfg.beta2, t));
     u.beta1 = m->cfg.beta1; u.beta2 = m->cfg.beta2; u.eps = m->cfg.eps;
     u.fin_on = 0;
+    u.xch = 0; u.link.world = 0;
     return u;
 }
 
@@ -1094,13 +1120,14 @@ static void tg_launch_rowpass(const TgUpdateArgs& u, int rows, int V, tg_stream_
 }
 
 static int tg_launch_update(tg_mapper* m, float lr, bool finalize, tg_stream_t stream = nullptr, int c0 = 0, int c1 = -1,
-                            bool rowpass = false) {
+                            bool rowpass = false, const TgPeerLink* link = nullptr) {
     const TgLayout& L = m->L;
     const bool whole = c1 < 0;
     if (whole) { stream = m->stream; c0 = 0; c1 = L.C; }
     TgUpdateArgs u = tg_update_args(m, lr, finalize, c0, c1);
     const bool x16 = (m->cfg.precision == TG_PREC_BF16) && !L.smallc;     // PrecBF16::X16 (the small-C kernels store X in fp32)
     u.fin_on = 0;
+    if (link) { u.xch = 1; u.link = *link; }                              // (fused sharded step: the row pairs are pushed from the kernel's tail)
     int extra_wg = 0;
     if (m->fin_pending && whole) { u.fin = m->fin_args; u.fin_on = 1; extra_wg = 1; m->fin_pending = false; }
     if (rowpass) {
@@ -1517,6 +1544,7 @@ struct tg_comm {
     // peer-memory transport (tg_peer_exchange, tg_kernels.h): this rank's mailbox, every rank's mailbox as mapped here
     unsigned char* box; unsigned char* peer[TG_PEER_MAX];
     size_t cap, box_bytes; unsigned seq; int peer_mode, connected;                   // peer_mode 0: off; 1: hipIpc handles; 2: raw pointers
+    size_t step_cap; unsigned step_seq; int colocated;                               // step area (tg_comm_peer_create_stepped): granules per (slot, rank), steps so far
     unsigned long long timeout_ticks;
     char shm_name[64];                                                               // (emulated build: the mailbox is a POSIX shm object)
 };
@@ -1543,15 +1571,17 @@ static unsigned long long tg_peer_timeout_ticks() {
     const double ms = (e && *e) ? atof(e) : 20000.0;
     return (unsigned long long)((ms > 1.0 ? ms : 1.0) * 1e5);          // 10-ns ticks
 }
-extern "C" int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out) {
-    if (!out || !handle64_out || world < 1 || world > TG_PEER_MAX || rank < 0 || rank >= world || capacity_floats < 1)
-        return tg_fail(TG_ERR_INVALID, "bad peer communicator arguments (1 <= world <= %d)", TG_PEER_MAX);
+extern "C" int tg_comm_peer_create_stepped(int world, int rank, size_t capacity_floats, size_t step_floats, int colocated, int same_process,
+                                    void* handle64_out, tg_comm** out) {
+    if (!out || !handle64_out || world < 1 || world > TG_PEER_MAX || rank < 0 || rank >= world || capacity_floats < 1 || colocated < 1)
+        return tg_fail(TG_ERR_INVALID, "bad peer communicator arguments (1 <= world <= %d, colocated >= 1)", TG_PEER_MAX);
     tg_comm* c = new (std::nothrow) tg_comm();
     if (!c) return tg_fail(TG_ERR_INVALID, "out of host memory");
     memset(c, 0, sizeof *c);
     c->world = world; c->rank = rank;
     c->cap = rup(capacity_floats, TG_PEER_CHUNK);
-    c->box_bytes = tg_peer_box_bytes(world, c->cap);
+    c->step_cap = rup(step_floats, 64); c->colocated = colocated;
+    c->box_bytes = tg_peer_box_bytes(world, c->cap, c->step_cap);
     c->peer_mode = same_process ? 2 : 1;
     c->timeout_ticks = tg_peer_timeout_ticks();
     memset(handle64_out, 0, 64);
@@ -1591,6 +1621,9 @@ extern "C" int tg_comm_peer_create(int world, int rank, size_t capacity_floats, 
     *out = c;
     return TG_OK;
 }
+extern "C" int tg_comm_peer_create(int world, int rank, size_t capacity_floats, int same_process, void* handle64_out, tg_comm** out) {
+    return tg_comm_peer_create_stepped(world, rank, capacity_floats, 0, 1, same_process, handle64_out, out);
+}
 // handles: world x 64 bytes, rank r's from tg_comm_peer_create (gathered over any out-of-band channel).  Collective in the sense that
 // every rank must have created its mailbox before anybody connects.
 extern "C" int tg_comm_peer_connect(tg_comm* c, const void* handles) {
@@ -1612,7 +1645,10 @@ extern "C" int tg_comm_peer_connect(tg_comm* c, const void* handles) {
         hipIpcMemHandle_t ih; memcpy(&ih, h, sizeof ih);
         void* p = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return tg_fail(TG_ERR_HIP, "hipIpcOpenMemHandle for rank %d's mailbox failed (%s)", r, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            for (int q = 0; q < r; ++q) if (q != c->rank && c->peer[q]) { (void)hipIpcCloseMemHandle(c->peer[q]); c->peer[q] = nullptr; }   // (what was opened so far)
+            return tg_fail(TG_ERR_HIP, "hipIpcOpenMemHandle for rank %d's mailbox failed (%s)", r, hipGetErrorString(e));
+        }
         c->peer[r] = (unsigned char*)p;
 #endif
     }
@@ -1770,6 +1806,61 @@ static int tg_exchange_row_stats(tg_mapper* m, float* hist_row) {
     return tg_merge(m, m->fp(L.o_gathered), m->comm->world, /*finalize=*/true, /*want_pair=*/false, hist_row, m->comm->rank);
 }
 
+// ---- spot shards: kernels that exchange with the other ranks themselves (peer transport with a step area, round 6) ----------------
+// Grid of a kernel whose workgroups WAIT for pushes of other ranks.  Deployment (one rank per device): callers launch their natural grid
+// (one workgroup per row: the dispatcher starts them in order).  Ranks that SHARE a device (the one-GPU tests; tg_comm_peer_create_stepped's
+// `colocated`): a waiting kernel must leave the device to the kernels of the ranks it waits for -- half of the CUs divided by the ranks,
+// one workgroup each, all co-resident, walking their rows with a grid stride.
+static int tg_polling_grid(tg_mapper* m, const void* fn, int nt, int lds, int want) {
+    int g;
+#ifdef TG_SIM
+    (void)fn; (void)nt; (void)lds;
+    g = 3;                                                   // (a few rows per workgroup: the grid-stride walk gets exercised)
+#else
+    static thread_local std::map<const void*, int> per_cu_of;
+    static thread_local int cus = 0;
+    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64; }
+    int& per_cu = per_cu_of[fn];
+    if (!per_cu) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, (size_t)lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; } }
+    const int col = m->comm ? m->comm->colocated : 1;
+    g = col > 1 ? cus / (2 * col) : cus * per_cu;
+#endif
+    if (g < 1) g = 1;
+    return g < want ? g : want;
+}
+
+static bool tg_grid_strided(const tg_mapper* m) {
+#ifdef TG_SIM
+    (void)m; return true;                                    // (the emulator always walks: the loop is what needs testing there)
+#else
+    return m->comm->colocated > 1;
+#endif
+}
+
+static TgPeerLink tg_step_link(tg_mapper* m) {
+    const tg_comm* c = m->comm; const TgLayout& L = m->L;
+    TgPeerLink k;
+    k.box = (unsigned char* const*)(m->ws + L.o_peertab);               // (the table tg_mapper_attach_comm left there)
+    k.world = c->world; k.rank = c->rank;
+    k.base = (unsigned long long)2 * c->world * c->cap; k.cap = c->step_cap; k.timeout_ticks = c->timeout_ticks;
+    k.seq = c->step_seq; k.slot = (int)(c->step_seq & 1u);
+    k.e2 = L.step_e2; k.e3 = L.step_e3; k.e1 = L.step_e1;
+    return k;
+}
+
+// the statistics of the new rows on a fused step: every rank's pairs arrive as granules (pushed from the tails of the update kernels);
+// tg_merge_stats_x polls for them at its head
+static int tg_merge_fused(tg_mapper* m, float* hist_row, const TgPeerLink& link) {
+    const TgLayout& L = m->L;
+    const TgMergeArgs a = tg_merge_args(m, nullptr, m->comm->world, /*finalize=*/true, /*want_pair=*/false, hist_row, m->comm->rank);
+    const int want = (L.C + 255) / 256;
+    const int grid = tg_grid_strided(m) ? tg_polling_grid(m, (const void*)tg_merge_stats_x, 256, 0, want) : want;
+    TG_LAUNCH(tg_merge_stats_x, grid, 1, 256, 0, m->stream, a, link);
+    tg_prof_mark(m, "tg_merge_stats");
+    TG_LAUNCH_CK();
+    return TG_OK;
+}
+
 extern "C" int tg_mapper_attach_comm(tg_mapper* m, tg_comm* comm) {
     if (!m || !m->ready || !comm) return tg_fail(TG_ERR_STATE, "mapper not ready or null communicator");
     const TgLayout& L = m->L;
@@ -1781,6 +1872,16 @@ extern "C" int tg_mapper_attach_comm(tg_mapper* m, tg_comm* comm) {
         return tg_fail(TG_ERR_INVALID, "spatial terms on spot shards: rank %d of %d must hold the spots from %d on (handle: %d ranks, offset %d)",
                        comm->rank, comm->world, comm->rank * L.Vmaxl, L.nranks, m->cfg.spot_offset);
     m->comm = comm;
+    // Round 6: on the peer transport with a step area the three exchanges of a step happen inside its kernels (tg_one_step_sharded).
+    // TG_PEER_FUSED=0 (environment) keeps the exchange kernels of round 5 (A / B measurements).
+    {
+        const char* e = getenv("TG_PEER_FUSED");
+        m->fused = comm->peer_mode && comm->step_cap >= L.step_floats && L.step_floats > 0 && !L.sp_shard && !(e && *e == '0');
+    }
+    if (comm->peer_mode) {                                       // every rank's mailbox as mapped here: the kernels' table (TgPeerLink::box)
+        static_assert(TG_PEER_MAX * sizeof(void*) <= 256, "the mailbox table has a 256-byte block");
+        TG_CK(tg_memcpy_h2d(m->ws + L.o_peertab, comm->peer, sizeof(void*) * (size_t)comm->world, m->stream));
+    }
     if (L.sp_shard) {
         // the spatial terms see the whole spot graph: gather the blocks of G once (the references W G, |W G_k|^2 and the autocorrelation
         // indicators of G are constants of the run), like Ghat every iteration
@@ -1802,24 +1903,41 @@ template <class PR>
 static int tg_one_step_sharded(tg_mapper* m, float lr, float* hist_row) {
     const TgLayout& L = m->L;
     int rc;
+    // fused (peer transport with a step area, round 6): no exchange launches -- every exchange happens inside the small kernel that produces
+    // or consumes its vector: E2 inside tg_gene_reduce, E3 inside tg_rowsum_parts, E1 pushed from the tail of the update kernel and polled at
+    // the head of the merge: 8 launches per step instead of 11, every sum in the same order as on the other transports (bit-identical).
+    // (Measured and NOT adopted, profiles/r06: E3 per row inside the update kernel -- at the head of the streaming kernel 164 + 9 + 7 -> 216 us,
+    //  inside a register-resident row kernel that also drops the GEMM's row-dot epilogue 220 + 164 -> 198 + 376 us: a round trip through the
+    //  fine-grained mailbox costs a row ~4 us, which no residency a 1 250-spot row allows can hide.)
+    const bool fused = m->fused;
+    TgPeerLink link;
+    link.world = 0;
+    if (fused) {
+        if (tg_stream_capturing(m->stream))              // (the sequence number of a step is a launch argument)
+            return tg_fail(TG_ERR_UNSUPPORTED, "a sharded step over the peer transport cannot be captured into a HIP graph");
+        m->comm->step_seq += 1;
+        link = tg_step_link(m);
+    }
     if ((rc = tg_launch_forward<PR>(m))) return rc;
-    if ((rc = tg_launch_ghat_stats(m))) return rc;
-    if ((rc = tg_exchange_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;        // E2: per-gene cosine statistics
+    if ((rc = tg_launch_ghat_stats(m, false, fused ? &link : nullptr))) return rc;
+    if (!fused && (rc = tg_exchange_all_reduce(m, m->fp(L.o_genestat), (size_t)2 * L.Kp))) return rc;   // E2: per-gene cosine statistics
     if (L.sp_shard && (rc = tg_exchange_all_gather(m, m->fp(L.o_Ghat), m->fp(L.o_GhatFull), (size_t)L.Vmaxl * L.Kp))) return rc;   // spatial terms: all of Ghat
     if ((rc = tg_launch_loss<PR>(m, hist_row))) return rc;                                    // (coefficients; dGhat operand image)
     tg_launch_bwd<PR>(m, m->stream, 0, L.nct);                                                // X + row-dot partials of this rank's spots
     tg_prof_mark(m, "tg_bwd_kernel");
-    tg_launch_rowsum(m, m->stream, 0, L.C);
+    tg_launch_rowsum(m, m->stream, 0, L.C, fused ? &link : nullptr);                          // fused: E3 inside
     tg_prof_mark(m, "tg_rowsum_parts");
     if (tg_launch_failed()) return tg_launch_status();
-    if ((rc = tg_exchange_all_reduce(m, m->fp(L.o_rowq), (size_t)(L.full ? TGP1_N : 1) * L.C))) return rc;   // E3: row dots (+ regulariser row sums)
-    if ((rc = tg_launch_update(m, lr, false))) return rc;       // Adam; local (max, sum exp); deferred history row by its extra workgroup
+    if (!fused && (rc = tg_exchange_all_reduce(m, m->fp(L.o_rowq), (size_t)(L.full ? TGP1_N : 1) * L.C))) return rc;   // E3: row dots (+ regulariser row sums)
+    if ((rc = tg_launch_update(m, lr, false, nullptr, 0, -1, false, fused ? &link : nullptr))) return rc;   // Adam; local (max, sum exp) [fused: pushed];
+                                                                                                            // deferred history row by its extra workgroup
     if (L.full) {                                               // the row sums are global now: every rank adds the same scalars
         tg_launch_hist_regs(m, m->stream, hist_row);
         tg_prof_mark(m, "tg_hist_regs");
     }
     if (m->cfg.mode == TG_MODE_CONSTRAINED && (rc = tg_launch_filter(m, true, lr, hist_row))) return rc;   // replicated F: same result on every rank
     m->step += 1;
+    if (fused) return tg_merge_fused(m, hist_row, link);        // E1 polled at the head of the merge
     return tg_exchange_row_stats(m, hist_row);                  // E1: statistics of the new rows (+ globalise the history row)
 }
 

@@ -80,6 +80,8 @@ template <class PR, class GE> TG_KERNEL void TG_LAUNCH_BOUNDS2(GE::NT, 2) tg_fwd
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce(TgGhatReduceArgs a) { tg_ghat_reduce_body(a); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_ghat_reduce_b(const TgGhatReduceArgs* argv) { tg_ghat_reduce_body(argv[blockIdx.z]); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body<64>(genepart, nrb, Kp, genestat); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_x(const float* genepart, int nrb, int Kp, float* genestat, TgPeerLink link) { tg_gene_reduce_body<64>(genepart, nrb, Kp, genestat, &link); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_tall_x(const float* genepart, int nrb, int Kp, float* genestat, TgPeerLink link) { tg_gene_reduce_body<16>(genepart, nrb, Kp, genestat, &link); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_tall(const float* genepart, int nrb, int Kp, float* genestat) { tg_gene_reduce_body<16>(genepart, nrb, Kp, genestat); }
 TG_KERNEL void TG_LAUNCH_BOUNDS(1024) tg_gene_reduce_b(const TgGeneReduceArgs* argv) {
     const TgGeneReduceArgs a = argv[blockIdx.z];

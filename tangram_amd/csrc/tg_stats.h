@@ -94,8 +94,10 @@ TG_DEV void tg_ghat_reduce_body(const TgGhatReduceArgs& a) {
 // (A latency-bound kernel: every thread walks nrb / groups row blocks; with 4 groups it took 29 us at 600 row blocks.  KX = 64:
 //  16 groups; KX = 16, for more than 512 row blocks: 64 groups and four times the workgroups -- 36 -> 12 us at 1 563 row blocks.)
 #define TG_GR_GROUPS 16
+// `link` (spot shard on the peer transport, round 6): the exchange of the statistics happens HERE -- the thread that owns gene k pushes its
+// two sums into every rank's mailbox and stores the rank-order sum of the world's granules: what an all-reduce after this kernel delivers.
 template <int KX>
-TG_DEV void tg_gene_reduce_body(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/) {
+TG_DEV void tg_gene_reduce_body(const float* genepart, int nrb, int Kp, float* genestat /*[2][Kp]*/, const TgPeerLink* link = nullptr) {
     constexpr int NG = 1024 / KX;
     TG_LDS_DECL;
     float* red = (float*)tg_lds;        // [NG][KX][2]
@@ -121,6 +123,11 @@ TG_DEV void tg_gene_reduce_body(const float* genepart, int nrb, int Kp, float* g
     if (grp == 0 && k < Kp) {
         float d = 0.f, n = 0.f;
         for (int g = 0; g < NG; ++g) { d += red[(g * KX + kx) * 2 + 0]; n += red[(g * KX + kx) * 2 + 1]; }
+        if (link) {
+            tg_link_push(*link, link->e2 + k, d);
+            tg_link_push(*link, link->e2 + Kp + k, n);
+            tg_link_sum2(*link, link->e2 + k, link->e2 + Kp + k, d, n);
+        }
         genestat[k] = d;
         genestat[Kp + k] = n;
     }

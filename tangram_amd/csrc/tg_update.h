@@ -24,6 +24,10 @@ struct TgUpdateArgs {
     float step_size, bc2_sqrt, beta1, beta2, eps;
     int fin_on;                                       // 1: the LAST workgroup of the grid computes the history scalars instead of a row
     TgFinalizeArgs fin;                               //    (tg_loss_scalars; see tg_dghat_emit<SELF>)
+    // spot shards on the peer transport with a step area (round 6): the row pairs (and the history workgroup's parts of the sums over spots)
+    // are pushed into every rank's mailbox from the tail of the update kernel; tg_merge_stats_x polls for them
+    int xch;                                          // 1: on; 0 everywhere else
+    TgPeerLink link;
 };
 
 // ---- the arithmetic of one element, shared by both update kernels -------------------------------------------------------------
@@ -84,19 +88,28 @@ TG_DEV void tg_row_stats_out(float tmax, float tsum, float* red, const TgUpdateA
     const float wsum = tg_wave_sum(tsum * tg_exp(tmax - wmax));        // (a thread without elements: 0 * exp(-big) = 0)
     if (lane == 0) { red[wave * 2] = wmax; red[wave * 2 + 1] = wsum; }
     __syncthreads();
-    if (t == 0) {
+    if (wave == 0) {
+        // every lane of wave 0 derives the pair (same reads, same order: the same bits in every lane); lane 0 writes it; on a spot shard of
+        // the peer transport (a.xch) it also travels now -- lane r < world stores the maximum into rank r's mailbox, lane world + r the
+        // sum -- and tg_merge_stats_x polls for it
         float mx = red[0];
         for (int w = 1; w < NW; ++w) mx = tg_fmax(mx, red[w * 2]);
         float z = 0.f;
         for (int w = 0; w < NW; ++w) z += red[w * 2 + 1] * tg_exp(red[w * 2] - mx);
-        a.pair_out[c] = mx;
-        a.pair_out[a.C + c] = z;
-        if (a.finalize) {
-            const float inz = 1.f / z;
-            a.new_shift[c] = mx;
-            a.new_invz[c] = inz;
-            a.new_mul[c] = inz;                                // (the constrained filter is folded in by tg_merge_stats)
-            a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
+        if (a.xch && lane < 2 * a.link.world) {
+            const int r = lane % a.link.world, second = lane / a.link.world;
+            tg_link_push_to(a.link, r, a.link.e1 + (second ? a.C : 0) + c, second ? z : mx);
+        }
+        if (lane == 0) {
+            a.pair_out[c] = mx;
+            a.pair_out[a.C + c] = z;
+            if (a.finalize) {
+                const float inz = 1.f / z;
+                a.new_shift[c] = mx;
+                a.new_invz[c] = inz;
+                a.new_mul[c] = inz;                            // (the constrained filter is folded in by tg_merge_stats)
+                a.new_scale[c] = (mx + tg_log(z)) * TG_LOG2E;
+            }
         }
     }
 }
@@ -117,7 +130,14 @@ TG_KERNEL void TG_LAUNCH_BOUNDS(NT) tg_adam_update(TgUpdateArgs a) {
     constexpr int NW = NT / 64;
     TG_LDS_DECL;
     float* red = (float*)tg_lds;          // [NW waves][2]  (history workgroup: [NW][5])
-    if (a.fin_on && blockIdx.x == gridDim.x - 1) { tg_loss_scalars<false>(a.fin, red); return; }
+    if (a.fin_on && blockIdx.x == gridDim.x - 1) {
+        tg_loss_scalars<false>(a.fin, red);
+        if (a.xch && threadIdx.x == 0 && a.fin.part_out) {     // spot shard, peer transport: this rank's parts of the sums over spots ride with
+            tg_link_push(a.link, a.link.e1 + 2 * (size_t)a.C, a.fin.part_out[0]);           // the row pairs (tg_row_stats_out)
+            tg_link_push(a.link, a.link.e1 + 2 * (size_t)a.C + 1, a.fin.part_out[1]);
+        }
+        return;
+    }
     const int c = a.c_begin + blockIdx.x, t = threadIdx.x;
     TgRowK rk;
     rk.sh = a.rshift[c]; rk.iz = a.rinvz[c];
@@ -339,25 +359,41 @@ struct TgRowsumArgs {
     const float* part; int nvt; int C; int np;
     float* rowq;               // [np][C] summed partials (row 0 = r_c)
     int c_begin, c_end;        // cells handled by this launch
+    int xch; TgPeerLink link;  // xch (spot shard, peer transport with a step area): the thread that owns a cell's sum pushes it into every rank's
+                               // mailbox and stores the rank-order sum of the world's granules: what an all-reduce after this kernel delivers
 };
 // 16 cells x 16 groups of spot tiles per workgroup: a cell's partials p = g, g + 16, ... side by side, then the groups in fixed order
 // (one thread per cell walking all V / 128 partials took 61 us at 50 000 spots and 18 rows of M)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_rowsum_parts(TgRowsumArgs a) {
     TG_LDS_DECL;
     float* red = (float*)tg_lds;                                 // [16][16]
-    const int r = threadIdx.x & 15, g = threadIdx.x >> 4, c = a.c_begin + blockIdx.x * 16 + r;
-    for (int q = 0; q < a.np; ++q) {
-        float s = 0.f;
-        if (c < a.c_end)
-            for (int p = g; p < a.nvt; p += 16) s += a.part[((size_t)p * a.np + q) * a.C + c];
-        red[g * 16 + r] = s;
-        __syncthreads();
-        if (g == 0 && c < a.c_end) {
-            float t = 0.f;
-            for (int i = 0; i < 16; ++i) t += red[i * 16 + r];
-            a.rowq[(size_t)q * a.C + c] = t;
+    float* loc = red + 256;                                      // xch: [np][16] this rank's sums of the block's cells
+    const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
+    // (a grid-stride walk over the blocks of 16 cells: one trip unless the grid was cut short -- ranks sharing a device, tg_polling_grid)
+    for (int blk = blockIdx.x; a.c_begin + blk * 16 < a.c_end; blk += (int)gridDim.x) {
+        const int c = a.c_begin + blk * 16 + r;
+        for (int q = 0; q < a.np; ++q) {
+            float s = 0.f;
+            if (c < a.c_end)
+                for (int p = g; p < a.nvt; p += 16) s += a.part[((size_t)p * a.np + q) * a.C + c];
+            red[g * 16 + r] = s;
+            __syncthreads();
+            if (g == 0 && c < a.c_end) {
+                float t = 0.f;
+                for (int i = 0; i < 16; ++i) t += red[i * 16 + r];
+                if (a.xch) loc[q * 16 + r] = t; else a.rowq[(size_t)q * a.C + c] = t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (a.xch) {                                             // the exchange, every (sum, cell) of the block at once: one round trip
+            const int q = threadIdx.x >> 4;
+            if (q < a.np && c < a.c_end) {
+                const size_t place = a.link.e3 + (size_t)q * a.C + c;
+                tg_link_push(a.link, place, loc[q * 16 + r]);
+                a.rowq[(size_t)q * a.C + c] = tg_link_sum(a.link, place);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -502,8 +538,49 @@ struct TgMergeArgs {
     float* hist; int rank;     // spot shards: history row to complete with the global spot sums (or null), this rank's index
     float lambda_g2, lambda_d; int has_density;
 };
-TG_DEV void tg_merge_stats_body(const TgMergeArgs& a) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+// PEER (spot shard on the peer transport, round 6): the ranks' blocks are not in `part` but arrive as granules in this rank's mailbox,
+// pushed from the tail of every rank's update kernel (tg_row_stats_out, the history workgroup): the poll of that exchange happens
+// here, at the head of the kernel that consumes it.  Same maxima, same sums in the same (rank) order as the gathered form.
+template <bool PEER>
+TG_DEV void tg_merge_stats_body(const TgMergeArgs& a, const TgPeerLink* link = nullptr) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if constexpr (PEER) {
+        if (a.hist && blockIdx.x == 0 && threadIdx.x == 0) {
+            float vg, kl;
+            tg_link_sum2(*link, link->e1 + 2 * (size_t)a.C, link->e1 + 2 * (size_t)a.C + 1, vg, kl);
+            float total = a.hist[TGH_TOTAL];
+            if (a.lambda_g2 != 0.f) { a.hist[TGH_VG] = vg; total -= a.lambda_g2 * vg; }
+            if (a.has_density) { a.hist[TGH_KL] = kl; total += a.lambda_d * kl; }
+            a.hist[TGH_TOTAL] = total;
+        }
+        // (a grid-stride walk: ranks that SHARE a device -- the one-GPU tests -- poll with few workgroups, see tg_polling_grid)
+        for (; c < a.C; c += (int)gridDim.x * 256) {
+        float pm[TG_PEER_MAX], pz[TG_PEER_MAX];
+        float mx = TG_NEG_BIG;
+#pragma unroll
+        for (int h = 0; h < TG_PEER_MAX / 8; ++h) {
+            if (8 * h >= a.nparts) break;
+            float vm[8], vz[8];
+            tg_link_get8x2(*link, link->e1 + c, link->e1 + a.C + c, 8 * h, vm, vz);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { pm[8 * h + q] = (8 * h + q < a.nparts) ? vm[q] : TG_NEG_BIG; pz[8 * h + q] = vz[q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx = tg_fmax(mx, pm[8 * h + q]);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int p = 0; p < TG_PEER_MAX; ++p) if (p < a.nparts) z += pz[p] * tg_exp(pm[p] - mx);
+        if (a.pair_out) { a.pair_out[c] = mx; a.pair_out[a.C + c] = z; }
+        if (a.rshift) {
+            const float iz = 1.f / z;
+            a.rshift[c] = mx;
+            a.rinvz[c] = iz;
+            a.rmul[c] = (a.fgate ? a.fgate[c] : 1.f) * iz;
+            a.rscale[c] = (mx + tg_log(z) - (a.fgate ? tg_log(a.fgate[c]) : 0.f)) * TG_LOG2E;
+        }
+        }
+        return;
+    }
     if (a.hist && blockIdx.x == 0 && threadIdx.x == 0) {
         const float* tail = a.part + 2 * (size_t)a.C;
         float vg = 0.f, kl = 0.f;
@@ -543,8 +620,9 @@ TG_DEV void tg_merge_stats_body(const TgMergeArgs& a) {
     }
 }
 
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) { tg_merge_stats_body(a); }
-TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats_b(const TgMergeArgs* argv) { tg_merge_stats_body(argv[blockIdx.z]); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats(TgMergeArgs a) { tg_merge_stats_body<false>(a); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats_b(const TgMergeArgs* argv) { tg_merge_stats_body<false>(argv[blockIdx.z]); }
+TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_merge_stats_x(TgMergeArgs a, TgPeerLink link) { tg_merge_stats_body<true>(a, &link); }
 
 // forward row constant of the bf16 path WITHOUT the constrained-mode filter: (max + ln Z) * log2(e)
 TG_KERNEL void TG_LAUNCH_BOUNDS(256) tg_plain_rscale(const float* rshift, const float* rinvz, int C, float* out) {

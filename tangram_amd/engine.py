@@ -80,9 +80,16 @@ class HipMapperEngine:
         cfg.pipeline_bands = int(pipeline_bands)
         cfg.bwd_tile = int(bwd_tile)
         cfg.spot_offset = int(spot_offset)
-        if s_exact is not False and s_exact != "auto":        # (True is refused: nobody may CLAIM exactness, the library checks it)
-            raise ValueError("s_exact must be False (always the general three-product path) or 'auto' (check S once at construction)")
-        cfg.s_exact_mode = 0 if s_exact is False else 1
+        # any falsy value (False, 0, numpy.False_, None): the general three-product path; "auto": the library checks S once.  True was
+        # accepted as "check" before round 5 and is again, with a warning -- nobody can CLAIM exactness, the library always checks.
+        if isinstance(s_exact, str):
+            if s_exact != "auto":
+                raise ValueError("s_exact must be False (always the general three-product path) or 'auto' (check S once at construction)")
+            s_exact = True
+        elif s_exact:
+            import warnings
+            warnings.warn("s_exact=True is treated as s_exact='auto': the library checks S itself", DeprecationWarning, stacklevel=3)
+        cfg.s_exact_mode = 1 if s_exact else 0
         for k, v in lam.items():
             setattr(cfg, k, float(v))
         cfg.target_count = float(target_count)

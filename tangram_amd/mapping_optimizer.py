@@ -265,6 +265,8 @@ class Mapper:
             run(n, learning_rate, hist, t)
             t += n
             if print_each and (t - 1) % print_each == 0 and not (self._sharded is not None and quiet):
+                if self._sharded is not None:
+                    self._sharded.checked()                  # (peer transport: never print a row an exchange gave up on)
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES])
             if val_each is not None and (t - 1) % val_each == 0:
@@ -399,6 +401,8 @@ class MapperConstrained:
             run(n, learning_rate, hist, t)
             t += n
             if print_each and (t - 1) % print_each == 0 and not (self._sharded is not None and self._rank != 0):
+                if self._sharded is not None:
+                    self._sharded.checked()
                 row = hist[t - 1].detach().cpu().numpy()
                 _print_terms([(name, float(row[col])) for name, col in _PRINT_NAMES_CONSTRAINED])
         if self._sharded is not None and not self._gather_result:

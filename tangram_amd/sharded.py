@@ -15,9 +15,13 @@ exchanges -- is issued by the C library inside `tg_mapper_step` (include/tangram
   * transport "peer" (round 5): no collective library at all -- every rank owns a mailbox in its HBM that its peers map (hipIpc), an
     exchange is ONE kernel on the handle's stream and ONE xGMI hop (8-byte {value, sequence number} granules stored into every
     mailbox, polled in the own one, summed in rank order): the latency of a kernel launch, not of a 2 (N - 1)-hop ring.
-    `transport="auto"` (the default) on an nccl group whose ranks share ONE node sets it up, runs a self-test against the group's
-    own all-reduce / all-gather on this very topology ("peer_checked"), and -- all ranks agreeing by an all-reduce of their
-    verdicts -- uses it; any failure (mailbox allocation, hipIpc mapping, a wrong or late result) falls back to "rccl", logged.
+    Round 6: with a STEP AREA in the mailbox (tg_comm_peer_create_stepped) a step launches no exchange kernel at all -- the per-gene statistics
+    are pushed and polled inside tg_gene_reduce, the row sums inside the update kernel (the row stays in registers across the exchange),
+    the row pairs are pushed from the update kernel's tail and polled at the head of the merge.  OPT-IN (`transport="peer_checked"`,
+    or TG_SHARD_TRANSPORT=peer_checked in the environment): set-up + a self-test against the group's own all-reduce / all-gather on
+    this very topology, all ranks agreeing on the verdict; any failure (mailbox allocation, hipIpc mapping, a wrong or late result)
+    falls back to "rccl", logged.  `transport="auto"` (the default) is RCCL on an nccl group: the peer transport has never crossed
+    xGMI (no box of any round had two GPUs), and a default must not rest on an unmeasured path (round-5 advisor).
   * transport "callbacks": the library calls back into this module, which runs the collective through any object with
     `all_reduce(t)` / `all_gather_into_tensor(out, t)` (torch.distributed with gloo in the CPU tests, an in-process communicator
     for several shards of one GPU in the GPU tests).
@@ -135,10 +139,13 @@ class ShardedMapperEngine:
         if transport in ("auto", "peer_checked"):
             is_nccl = comm is None and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
             base = "rccl" if (is_nccl and not _capi.is_emulated() and self.eng.device.type == "cuda") else "callbacks"
-            # Default on an nccl group of ONE node: the peer transport, IF its self-test on this very topology agrees with the
-            # group's own collectives (every rank decides the same, by an all-reduce of the verdicts); otherwise RCCL.
+            # Default: the process group's own transport (RCCL on an nccl group).  The peer transport is opt-in ("peer_checked": only after
+            # its self-test on this very topology, every rank deciding the same; "peer": unconditionally) until it has been run and
+            # timed on a node with more than one GPU.
             if transport == "auto":
-                transport = "peer_checked" if (base == "rccl" and self.world > 1 and self.world <= 16 and _single_node(group, self.eng.device)) else base
+                transport = base
+            elif not (self.world <= 16 and _single_node(group, self.eng.device)):
+                transport = base                         # (mailboxes are mapped through hipIpc: one node, at most 16 ranks)
             fallback = base
         self._error = None
         self._init_transport(lib, group, transport, comm, fallback)
@@ -195,12 +202,17 @@ class ShardedMapperEngine:
         dev = self.eng.device
         same = bool(getattr(self.pycomm, "same_process", False))
         cap = max(6 * self.eng.C + 64, 2 * (self.eng.K + 1024))               # the longest per-step vector; longer ones travel in pieces
+        # Messages of megabytes (the per-step all-gather of Ghat in runs with spatial terms) go in `cap`-sized pieces through the same
+        # mailbox; the step area behind it (sizes.peer_step_floats) is what lets a step run its three exchanges inside its kernels.
+        step = int(self.eng.sizes.peer_step_floats)
+        colocated = self._colocated_ranks(dev)
+        self.mailbox_bytes = 256 + 2 * self.world * (cap + step + 1024) * 8      # (reported: it is the one allocation outside tg_query_sizes)
         handle, ok, why = ct.c_void_p(), True, ""
         ctx = torch.cuda.device(dev) if dev.type == "cuda" else _Null()
         with ctx:
             buf = ct.create_string_buffer(64)
             try:
-                _capi.check(lib.tg_comm_peer_create(self.world, self.rank, cap, int(same), buf, ct.byref(handle)))
+                _capi.check(lib.tg_comm_peer_create_stepped(self.world, self.rank, cap, step, colocated, int(same), buf, ct.byref(handle)))
             except Exception as e:        # noqa: BLE001
                 ok, why = False, f"create: {e}"
             if not self._all_agree(ok):
@@ -239,6 +251,26 @@ class ShardedMapperEngine:
                 log.info("tangram_amd: peer-memory transport verified on this node (%d ranks)", self.world)
         return handle
 
+    def _colocated_ranks(self, dev):
+        """How many ranks of the communicator run on THIS rank's device (1 in deployment; the one-GPU tests: all of them)."""
+        if self.world == 1:
+            return 1
+        import socket
+        import zlib
+        ident = socket.gethostname()
+        if dev.type == "cuda":
+            pr = torch.cuda.get_device_properties(dev)
+            ident += "|" + str(getattr(pr, "uuid", "")) + "|" + "/".join(str(getattr(pr, k, "")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        else:
+            ident += "|cpu"                              # (emulated build: every process is its own "device")
+            return 1
+        mine = torch.tensor([float(zlib.crc32(ident.encode()) % (1 << 23))], dtype=torch.float32)
+        if isinstance(self.pycomm, DistComm) and dist.get_backend(self.group) == "nccl":
+            mine = mine.to(dev)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        self.pycomm.all_gather(outs, mine)
+        return max(1, sum(1 for o in outs if float(o.item()) == float(mine.item())))
+
     def _peer_selftest(self, lib, handle, cap):
         """A few exchanges of the sizes a step moves (and one longer than the mailbox: pieces), against torch.distributed's own
         all-reduce / all-gather on the same vectors; polls bounded to 3 s while testing."""
@@ -252,9 +284,15 @@ class ShardedMapperEngine:
             ref = x.clone()
             self.pycomm.all_reduce(ref)
             got = x.clone()
-            _capi.check(lib.tg_comm_all_reduce_sum(handle, got.data_ptr(), n, stream))
             outs = torch.empty(self.world * n, dtype=torch.float32, device=dev)
-            _capi.check(lib.tg_comm_all_gather(handle, x.data_ptr(), outs.data_ptr(), n, stream))
+            # a failure of THIS rank's library calls must not desynchronise the process group: every rank keeps issuing the same
+            # sequence of group collectives and the verdicts are only compared at the end (round-5 advisor)
+            if good:
+                try:
+                    _capi.check(lib.tg_comm_all_reduce_sum(handle, got.data_ptr(), n, stream))
+                    _capi.check(lib.tg_comm_all_gather(handle, x.data_ptr(), outs.data_ptr(), n, stream))
+                except Exception:        # noqa: BLE001
+                    good = False
             ref_g = torch.empty(self.world * n, dtype=torch.float32, device=dev)
             self.pycomm.all_gather_into_tensor(ref_g, x)
             self.eng._sync()
@@ -320,6 +358,14 @@ class ShardedMapperEngine:
     def run(self, n_steps, lr, history=None, first_row=0):
         """`n_steps` sharded iterations in ONE call of the C library; the history rows are global (identical on every rank)."""
         self._guard(self.eng.step, n_steps, lr, history, first_row)
+        self._steps_since_check = getattr(self, "_steps_since_check", 0) + n_steps
+
+    def checked(self):
+        """Peer transport: synchronise and raise if any exchange since the last check gave up waiting (callers that consume history rows
+        or validation numbers DURING a run -- print_each / val_each -- call this before they trust them)."""
+        if getattr(self, "_steps_since_check", 0):
+            self._steps_since_check = 0
+            self.peer_check()
 
     def step(self, lr, history_row=None):
         hist = history_row.view(1, -1) if history_row is not None else None
@@ -328,7 +374,9 @@ class ShardedMapperEngine:
     def validate(self):
         """`_val_loss_fn` of the current mapping over ALL spots (collective: every rank calls it, every rank gets the same four
         numbers): per-gene sums, spot-cosine sum, entropy sum and non-zero fractions are all-reduced inside tg_mapper_validate."""
-        return self._guard(self.eng.validate)
+        out = self._guard(self.eng.validate)
+        self.checked()
+        return out
 
     def finalize_history(self, history):
         """Kept for callers of the earlier API: the rows written by `run` are already the global history."""
@@ -378,6 +426,7 @@ class ShardedMapperEngine:
 
     def project_full(self, S_all=None, unfiltered=True):
         """softmax(M)^T S for every spot: each rank projects onto its own spots, the row blocks are gathered -> [V_total, K]."""
+        self.checked()
         Gh = self.eng.project() if S_all is None else self.eng.project_genes(S_all, unfiltered=unfiltered)
         return self._gather_columns(Gh.t().contiguous()).t().contiguous()
 

@@ -28,7 +28,7 @@ def test_hip_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.tg_abi_version.restype = ctypes.c_int
     from tangram_amd import _capi
-    assert lib.tg_abi_version() == _capi.TG_ABI_VERSION == 5
+    assert lib.tg_abi_version() == _capi.TG_ABI_VERSION == 6
 
 
 def test_argument_errors_are_reported_not_aborted():

@@ -18,7 +18,7 @@ def test_native_library_is_the_one_running():
     from tangram_amd import _capi
     assert torch.cuda.is_available()
     assert not _capi.is_emulated()
-    assert _capi.lib().tg_abi_version() == _capi.TG_ABI_VERSION == 5
+    assert _capi.lib().tg_abi_version() == _capi.TG_ABI_VERSION == 6
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16"])
