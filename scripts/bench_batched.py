@@ -82,6 +82,26 @@ def main():
         out[label] = {"seconds": t, "speedup": t_seq / t, "bit_identical_to_sequential": bool(same)}
         for m in ms:
             m.release()
+    # --- the reference's tuning caller (mapping_parameter_tuning.py:110-129): three seeds of ONE problem with a validation split and
+    # val_each = 1, one after the other (what the reference does) vs in one tg_batch that pauses at every validation epoch
+    tr, va = np.arange(0, K - 10), np.arange(K - 10, K)
+    def seed_builder(seed):
+        return lambda: mo.Mapper(S=S_all[:, :K], G=G_all[:, :K], d=d, d_source=ds, lambda_d=1, train_genes_idx=tr, val_genes_idx=va, device=dev, random_state=seed)
+    sb = [seed_builder(s) for s in (1, 2, 3)]
+    ep = min(EPOCHS, 300)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    seq = [b().train(num_epochs=ep, learning_rate=0.1, print_each=None, val_each=1) for b in sb]
+    torch.cuda.synchronize()
+    t_seq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res, ms = train_many(sb, ep, 0.1, device=dev, val_each=1)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    same = all(np.array_equal(a[0], b[0]) and all(list(map(float, a[1][k])) == list(map(float, b[1][k])) for k in ("main_loss", "val_gene_sim")) for a, b in zip(seq, res))
+    out["tuning_three_seeds_val_each_1"] = {"epochs": ep, "sequential_s": t_seq, "train_many_batched_s": t, "speedup": t_seq / t, "bit_identical_to_sequential": bool(same)}
+    for m in ms:
+        m.release()
     print(json.dumps(out))
 
 

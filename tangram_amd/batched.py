@@ -11,7 +11,7 @@ per-mapping kernel arguments into device arrays and adds a batch index to the gr
 (blockIdx.z = mapping).  Results are the bits of training the same mappings one by one: nothing is shared between them.
 `Mapper`s batch with `Mapper`s, `MapperConstrained`s with `MapperConstrained`s (utils.py:576-600 passes any `mode`).
 Mappings that are not batched (a shape of their own, spatial terms, more than 16 384 spots, more than 2^25 cells x spots -- one
-such mapping fills the GPU and a batch of them measured slower than one after the other --, `val_each`, or a group the C library
+such mapping fills the GPU and a batch of them measured slower than one after the other --, or a group the C library
 refuses) are trained by one host thread per mapping (the C ABI releases the GIL; different handles may be driven from different
 threads); `batched=False` additionally gives every mapping a HIP stream of its own.
 """
@@ -91,17 +91,44 @@ def _batch_key(m):
             c.beta1, c.beta2, c.tile_size, c.fwd_splits)
 
 
-def _train_batched(mappers, num_epochs, learning_rate):
+def _train_batched(mappers, num_epochs, learning_rate, val_each=None):
+    """`val_each` (Mapper only; the tuning driver trains its three seeds with val_each = 1, mapping_parameter_tuning.py:110-129): the batch
+    advances to the next validation epoch in one call, every handle's `_val_loss_fn` numbers are enqueued into a device table
+    (tg_mapper_validate, no synchronisation) and the batch goes on -- the per-handle sequence of calls, hence the bits, of
+    `Mapper.train(val_each=...)` on each mapping alone."""
+    from .mapping_optimizer import _VAL_KEYS
     batch = MapperBatch(mappers)
-    hists = batch.new_histories(max(int(num_epochs), 1))
-    batch.step(int(num_epochs), learning_rate, hists, 0)
+    num_epochs = int(num_epochs)
+    hists = batch.new_histories(max(num_epochs, 1))
+    vals = None
+    if val_each is not None:
+        n_val = sum(1 for t in range(1, num_epochs + 1) if (t - 1) % val_each == 0)
+        vals = [torch.empty((max(n_val, 1), 4), dtype=torch.float32, device=m._engine.device) for m in mappers]
+    t, iv = 0, 0
+    while t < num_epochs:
+        if val_each is not None:
+            stop = t if t % val_each == 0 else (t // val_each + 1) * val_each      # last epoch of this chunk (inclusive), like Mapper.train
+            n = min(stop, num_epochs - 1) - t + 1
+        else:
+            n = num_epochs - t
+        batch.step(n, learning_rate, hists, t)
+        t += n
+        if val_each is not None and (t - 1) % val_each == 0:   # reference :398-403: after optimizer.step() of epoch t - 1
+            for m, v in zip(mappers, vals):
+                m._engine.validate_into(v[iv])
+            iv += 1
     out = []
-    for m, h in zip(mappers, hists):
+    for j, (m, h) in enumerate(zip(mappers, hists)):
         if type(m).__name__ == "MapperConstrained":            # train() -> (mapping, filter, history) (mapping_utils.py:387-389)
             P, F = m._engine.result(with_filter=True)
             out.append((P.detach().cpu().numpy(), F.detach().cpu().numpy(), m._history_dict(h[:num_epochs])))
         else:
-            out.append((m._engine.result().detach().cpu().numpy(), m._history_dict(h[:num_epochs])))
+            history = m._history_dict(h[:num_epochs])
+            if vals is not None:
+                for row in vals[j][:iv].detach().cpu().numpy():
+                    for k, x in zip(_VAL_KEYS, row):
+                        history[k].append(float(x))
+            out.append((m._engine.result().detach().cpu().numpy(), history))
     batch.close()
     return out
 
@@ -112,8 +139,8 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
     builders: callables, each returning a `Mapper` / `MapperConstrained`.  They are called one after the other on the
               calling thread (the reference's initialisation draws from the global NumPy RNG, `np.random.seed(random_state)`,
               which must not be interleaved).
-    batched:  "auto" (default): mappings that can share a `tg_batch` (one class, one shape, no spatial terms, <= 16 384 spots, no
-              `val_each`) advance in ONE launch per kernel; the others -- and any group the C library refuses -- get a host
+    batched:  "auto" (default): mappings that can share a `tg_batch` (one class, one shape, no spatial terms, <= 16 384 spots)
+              advance in ONE launch per kernel -- `val_each=k` (Mapper) included: the batch pauses at every validation epoch; the others -- and any group the C library refuses -- get a host
               thread each, their kernels sharing the common creation stream.  False: every mapper is created on a HIP stream
               of its own and trained by its own host thread (`max_concurrent` at a time): kernels of different mappings overlap.
     Returns the list of `mapper.train(...)` results (in the order of `builders`) and the mappers themselves."""
@@ -121,18 +148,22 @@ def train_many(builders, num_epochs, learning_rate=0.1, max_concurrent=4, device
     builders = list(builders)
     n = len(builders)
     results, mappers = [None] * n, [None] * n
-    if batched and not train_kwargs.get("val_each"):
+    val_each = train_kwargs.get("val_each")
+    if batched and set(train_kwargs) <= {"val_each"}:
         with (torch.cuda.device(device) if device.type == "cuda" else _null()):
             for i in range(n):
                 mappers[i] = builders[i]()
             groups = {}
             for i, m in enumerate(mappers):
-                groups.setdefault(_batch_key(m) or ("single", i), []).append(i)
+                key = _batch_key(m)
+                if val_each is not None and type(m).__name__ != "Mapper":          # (MapperConstrained.train has no val_each: let it say so)
+                    key = None
+                groups.setdefault(key or ("single", i), []).append(i)
             rest = []
             for key, idx in groups.items():
                 if key[0] != "single" and len(idx) > 1:
                     try:
-                        for i, r in zip(idx, _train_batched([mappers[i] for i in idx], num_epochs, learning_rate)):
+                        for i, r in zip(idx, _train_batched([mappers[i] for i in idx], num_epochs, learning_rate, val_each)):
                             results[i] = r
                         continue
                     except (RuntimeError, ValueError) as e:             # refused by tg_batch_create: nothing has been stepped yet

@@ -279,6 +279,11 @@ class HipMapperEngine:
         self._call(self._lib.tg_mapper_validate, self._h, out.data_ptr(), tensors=(out,))
         return [float(x) for x in out.cpu().numpy()]
 
+    def validate_into(self, out):
+        """The same four numbers into `out` (4 float32 on the device), enqueued on the handle's stream: no copy, no synchronisation
+        (a batch of mappings validated every epoch reads all its rows back once, at the end)."""
+        self._call(self._lib.tg_mapper_validate, self._h, out.data_ptr(), tensors=(out,))
+
     def logits(self):
         """Views of M / Adam m / Adam v ([C, pitch] float32, columns >= V are padding)."""
         pm, p1, p2 = ct.c_void_p(), ct.c_void_p(), ct.c_void_p()

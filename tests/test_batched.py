@@ -98,6 +98,45 @@ def test_batched_constrained_folds_emulated(sim):
     check_batched_constrained("cpu", "fp32", C=14, K=9, V=70, B=3, epochs=5, tol_loss=1e-5, tol_P=2e-5)
 
 
+def check_batched_tuning_seeds(device, precision, C, K, V, epochs, val_each):
+    """The reference's tuning caller (mapping_parameter_tuning.py:110-129): THREE seeds of one problem, train / validation gene
+    split, `val_each=1` -- trained in ONE tg_batch that pauses at every validation epoch, against the same three mappings trained
+    alone: all nine history keys and the mapping, bit for bit."""
+    import tangram_amd as tg
+    import tangram_amd.mapping_optimizer as mo
+    from tangram_amd.batched import _batch_key
+    from oracle import tangram_oracle as orc
+    data = orc.make_synthetic(C, K, V, seed=21)
+    tr = np.arange(0, K - 3)
+    va = np.arange(K - 3, K)
+    kw = dict(S=data["S"], G=data["G"], d=data["d"], train_genes_idx=tr, val_genes_idx=va, lambda_d=1, lambda_g1=1, lambda_g2=0.5)
+
+    def builder(seed):
+        return lambda: mo.Mapper(device=device, random_state=seed, gemm_precision=precision, **kw)
+
+    seeds = (1, 2, 3)                      # (the reference's seeds are 0, 1, 2; seed 0 means "unseeded" there, :148 -- not comparable)
+    res, mappers = tg.train_many([builder(s) for s in seeds], epochs, 0.1, device=device, val_each=val_each)
+    assert len({_batch_key(m) for m in mappers}) == 1 and _batch_key(mappers[0]) is not None
+    assert len({m._engine.logits()[3] for m in mappers}) == 1                # they were stepped together
+    solo = [builder(s)().train(num_epochs=epochs, learning_rate=0.1, print_each=None, val_each=val_each) for s in seeds]
+    n_val = sum(1 for t in range(1, epochs + 1) if (t - 1) % val_each == 0)
+    keys = ("total_loss", "main_loss", "vg_reg", "kl_reg", "entropy_reg", "val_total_loss", "val_gene_sim", "val_sp_sparsity_weighted_sim", "val_entropy")
+    for i in range(3):
+        P, hist = res[i]
+        np.testing.assert_array_equal(P, solo[i][0], err_msg=f"seed {seeds[i]}: batch != the mapping trained alone")
+        assert set(hist) == set(solo[i][1]) == set(keys)
+        for k in keys:
+            a, b = np.array(hist[k], dtype=np.float64), np.array(solo[i][1][k], dtype=np.float64)
+            assert len(a) == len(b) == (n_val if k.startswith("val_") else epochs), k
+            np.testing.assert_array_equal(a, b, err_msg=f"seed {seeds[i]}: {k}")
+        assert np.isfinite(np.array(hist["val_gene_sim"], dtype=np.float64)).all()
+
+
+def test_batched_tuning_seeds_with_val_each_emulated(sim):
+    check_batched_tuning_seeds("cpu", "fp32", C=14, K=12, V=70, epochs=5, val_each=1)
+    check_batched_tuning_seeds("cpu", "bf16x3", C=10, K=9, V=40, epochs=7, val_each=3)
+
+
 def test_batched_folds_emulated(sim):
     check_batched("cpu", "fp32", C=14, K=9, V=70, B=3, epochs=5, lam=dict(lambda_d=1, lambda_g1=1, lambda_g2=0.5), tol_loss=1e-5, tol_P=2e-5)
     check_batched("cpu", "bf16x3", C=10, K=6, V=40, B=2, epochs=3, lam=dict(lambda_d=1, lambda_g1=1, lambda_r=1e-3, lambda_l2=1e-5),

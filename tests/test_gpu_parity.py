@@ -357,6 +357,14 @@ def test_batched_mappings(precision):
                       tol_loss=tol["loss"], tol_P=tol["P"])
 
 
+def test_batched_tuning_seeds_with_val_each():
+    """f-3, the reference's tuning caller (mapping_parameter_tuning.py:110-129): three seeds with val_each=1 in ONE tg_batch give the
+    histories (all nine keys) and mappings of three solo runs bit for bit -- at the clusters-mode shape and on the GEMM kernels."""
+    from tests.test_batched import check_batched_tuning_seeds
+    check_batched_tuning_seeds(DEV, "bf16x3", C=18, K=60, V=1300, epochs=10, val_each=1)
+    check_batched_tuning_seeds(DEV, "bf16x3", C=1500, K=40, V=900, epochs=6, val_each=2)
+
+
 def test_batched_constrained_mappings():
     """tg_batch of MapperConstrained handles on the GPU (cross_val with mode='constrained', utils.py:576-600): 6 folds in one launch
     per kernel incl. the filter's Adam step and the re-folding of the new filters, bit-identical to the folds trained alone and
