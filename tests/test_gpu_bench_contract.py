@@ -33,6 +33,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     roof = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof) and roof["bound"] in ("hbm", "mfma")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
+    # round 6: the line describes the device state it was measured in
+    assert d["value_long"]["steps"] >= 20 and d["value_long"]["value"] > 0 and abs(d["value_long"]["value"] * d["value_long"]["ms_per_step"] - 1000.0) < 1e-3
+    assert 0.05 < roof["update_TBps_actual"] < 8.0 and "update_traffic_source" in roof
     cpu = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1
 
