@@ -177,7 +177,8 @@ def _full_reference(ref_mo, name):
                 count[0] += 1
                 if count[0] in (FULL_EPOCHS, SHARD_EPOCHS, LONG_EPOCHS):
                     snaps[count[0]] = optimizer.param_groups[0]["params"][0].detach().numpy().copy()
-            handle = torch.optim.optimizer.register_optimizer_step_post_hook(after_step)
+            import torch.optim.optimizer as _tho
+            handle = _tho.register_optimizer_step_post_hook(after_step)
             try:
                 P_long, hist = m.train(num_epochs=LONG_EPOCHS, learning_rate=0.1, print_each=None)
             finally:
