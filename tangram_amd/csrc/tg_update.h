@@ -552,6 +552,10 @@ TG_DEV void tg_merge_stats_body(const TgMergeArgs& a, const TgPeerLink* link = n
             if (a.lambda_g2 != 0.f) { a.hist[TGH_VG] = vg; total -= a.lambda_g2 * vg; }
             if (a.has_density) { a.hist[TGH_KL] = kl; total += a.lambda_d * kl; }
             a.hist[TGH_TOTAL] = total;
+            // an exchange of this rank has given up waiting for a peer (status word raised): the step's numbers are garbage -- say so in the
+            // history row itself, not only in tg_comm_peer_status (a caller that prints or consumes rows during a long run sees NaN at once)
+            if (tg_sys_load_u32((const unsigned*)link->box[link->rank]) != 0u)
+                for (int i = 0; i < TGH_NTERMS; ++i) a.hist[i] = __builtin_nanf("");
         }
         // (a grid-stride walk: ranks that SHARE a device -- the one-GPU tests -- poll with few workgroups, see tg_polling_grid)
         for (; c < a.C; c += (int)gridDim.x * 256) {
