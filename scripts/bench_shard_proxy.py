@@ -30,18 +30,21 @@ def main():
              (30000, 1000, 10000, 4, "bf16x3", "rccl"), (30000, 1000, 10000, 4, "bf16x3", "peer"),
              (30000, 1000, 10000, 2, "bf16x3", "rccl"), (30000, 1000, 10000, 2, "bf16x3", "peer"),
              (30000, 1000, 10000, 8, "bf16", "rccl"), (30000, 1000, 10000, 8, "bf16", "peer"))
+    # experiments (not in the default list): "rccl+fsN" = the forward cut into N stream-K pieces per gene tile (fwd_splits = -N)
+    cases = cases + tuple((30000, 1000, 10000, 8, "bf16x3", a) for a in sys.argv[1:] if a.startswith("rccl+fs"))
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for (C, K, V, parts, prec, tname) in cases:
         if only and not any(o in f"{parts}_{prec}_{tname}" for o in only):
             continue
-        transport = "peer" if tname.startswith("peer") else tname
+        transport = "peer" if tname.startswith("peer") else tname.split("+")[0]
+        fs = -int(tname.split("+fs")[1]) if "+fs" in tname else 0
         os.environ["TG_PEER_FUSED"] = "0" if tname == "peer_kernels" else "1"
         os.environ["TG_ROWPASS_PERSIST"] = "1" if tname.endswith("+persist") else "0"
         Vl = V // parts
         w = make_workload(C, K, V, dev, seed=0)
         M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous()
         e = ShardedMapperEngine(w["S"], w["G"][:Vl].contiguous(), M0, w["d"][:Vl].contiguous(), n_spots_total=V,
-                                device=dev, precision=prec, lambdas=dict(lambda_g1=1.0, lambda_d=1.0), transport=transport)
+                                device=dev, precision=prec, lambdas=dict(lambda_g1=1.0, lambda_d=1.0), transport=transport, fwd_splits=fs)
         n = 100
         hist = e.eng.new_history(n)
         e.run(10, 0.1)

@@ -13,6 +13,11 @@ TOL = {
     #           per-epoch |d loss|   max|dP|   relFro(P^T S)
     "fp32":   dict(loss=1e-5, P=2e-4, ghat=1e-4),
     "bf16x3": dict(loss=1e-5, P=2e-4, ghat=1e-4),
+    # bf16, max|dP| on the SMALL cases (tens to hundreds of spots: single probabilities of 0.1 - 1): calibrated in round 6 by running the 29
+    # plain-bf16 cases of the GPU suite under shrinking bounds (scripts/gpu_r06f.sh, profiles/r06/run4_bf16_tolerance_scan): 28 pass at
+    # 2e-2, 26 at 1e-2, 18 at 1e-3; the largest measured value is 3.5e-2 (golden constrained_entropy, 500 epochs), then 1.33e-2 (live
+    # reference, spatial terms) and 1.26e-2 (golden cells_autocorr): the bound is 1.4 x the largest measurement, not a formality.  (At
+    # full size the meaningful bound is relative: FULL_BOUNDS in tests/test_gpu_live_reference.py.)
     "bf16":   dict(loss=1e-3, P=float(os.environ.get("TG_TOL_BF16_P", 5e-2)), ghat=1e-2),      # (environment: the scan that calibrated the bound)
 }
 
