@@ -30,14 +30,18 @@ def main():
              (30000, 1000, 10000, 4, "bf16x3", "rccl"), (30000, 1000, 10000, 4, "bf16x3", "peer"),
              (30000, 1000, 10000, 2, "bf16x3", "rccl"), (30000, 1000, 10000, 2, "bf16x3", "peer"),
              (30000, 1000, 10000, 8, "bf16", "rccl"), (30000, 1000, 10000, 8, "bf16", "peer"))
-    # experiments (not in the default list): "rccl+fsN" = the forward cut into N stream-K pieces per gene tile (fwd_splits = -N)
-    cases = cases + tuple((30000, 1000, 10000, 8, "bf16x3", a) for a in sys.argv[1:] if a.startswith("rccl+fs"))
-    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    # experiments (not in the default list), as arguments "parts,precision,transport+fsN" (the forward cut into N stream-K pieces per gene
+    # tile: fwd_splits = -N) or "...+eqN" (N equal ranges per spot tile: fwd_splits = N)
+    exp = [a.split(",") for a in sys.argv[1:] if a.count(",") == 2]
+    cases = cases + tuple((30000, 1000, 10000, int(p_), pr, tn) for p_, pr, tn in exp)
+    only = [a for a in sys.argv[1:] if not a.startswith("-") and a.count(",") != 2]
+    if exp and not only:
+        only = ["(experiments only)"]
     for (C, K, V, parts, prec, tname) in cases:
-        if only and not any(o in f"{parts}_{prec}_{tname}" for o in only):
+        if only and not any(o in f"{parts}_{prec}_{tname}" for o in only) and [str(parts), prec, tname] not in exp:
             continue
         transport = "peer" if tname.startswith("peer") else tname.split("+")[0]
-        fs = -int(tname.split("+fs")[1]) if "+fs" in tname else 0
+        fs = -int(tname.split("+fs")[1]) if "+fs" in tname else (int(tname.split("+eq")[1]) if "+eq" in tname else 0)
         os.environ["TG_PEER_FUSED"] = "0" if tname == "peer_kernels" else "1"
         os.environ["TG_ROWPASS_PERSIST"] = "1" if tname.endswith("+persist") else "0"
         Vl = V // parts

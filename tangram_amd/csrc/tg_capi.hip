@@ -167,20 +167,31 @@ static int tg_choose_units(int nvt, int nkt, int nsteps, int slots, int precisio
     const long long G = (long long)nvt * nsteps;
     int best = nvt;
     double best_cost = 1e30;
-    auto consider = [&](long long units, bool aligned) {
+    auto consider = [&](long long units, bool aligned, double partial_rate = 1.5e6) {
         if (units < 1 || units > G || G / units < (units > nvt ? 8 : 1)) return;        // keep >= 8 contraction steps per piece
         const long long wgs = units * nkt, rounds = (wgs + slots - 1) / slots, segs = (aligned ? units : units + nvt) * nkt;
         const double steps = (double)G / (double)units;
-        const double cost = (double)rounds * (steps * t_step + 8.0 * (double)segs / (double)wgs) + (double)segs * (double)tile_bytes * 2.0 / 1.5e6;
+        const double cost = (double)rounds * (steps * t_step + 8.0 * (double)segs / (double)wgs) + (double)segs * (double)tile_bytes * 2.0 / partial_rate;
         if (cost < best_cost * 0.995) { best_cost = cost; best = (int)units; }
     };
     for (int s = 1; s <= 32; ++s) consider((long long)nvt * s, true);
     // stream-K pieces: whole rounds of the chip, and a piece length whose start offsets repeat every 8 pieces (units | 8 nvt), so
     // that the pieces of one XCD walk their tiles in step and share S^T through its L2 (tg_fwd_unit_map)
+    bool any_streamk = false;
     for (int r = 1; r <= 3; ++r) {
         const long long u = (long long)slots * r / nkt;
-        if (((long long)slots * r) % nkt == 0 && u > 0 && (8LL * nvt) % u == 0 && u % nvt != 0) consider(u, false);
+        if (((long long)slots * r) % nkt == 0 && u > 0 && (8LL * nvt) % u == 0 && u % nvt != 0) { consider(u, false); any_streamk = true; }
     }
+    // Round 6: shapes without such a piece length (a spot shard: 10 / 20 / 40 spot tiles) fell back to equal ranges per tile -- 12 x 10 x 2 =
+    // 240 workgroups on a 1/8 shard of cfg2, 6 % of the chip idle.  ONE exact round of stream-K pieces without the XCD alignment measures
+    // faster there: forward 190 -> 177 us at 1/8, 344 -> 321 at 1/4, 658 -> 624 at 1/2 of cfg2, fp32 651 -> 614, 30 000 x 1 000 x 3 300
+    // 498 -> 415 (two or three rounds lose) -- but SLOWER with ONE gene tile (26 431 x 249 x 9 852: 349 -> 377 us) and with short pieces
+    // (8 000 x 500 x 5 000 in bf16, 19 steps per piece: 60 -> 68 us): profiles/r06/run5_shard_forward.  Hence: only where the equal-ranges
+    // choice is itself a single, partly filled round, several gene tiles share an M panel, and a piece is at least 64 steps long; its extra
+    // partial segments priced at what tg_ghat_reduce really streams them at (3.7 - 4.8 TB/s since round 3, not the 1.5 this model was
+    // first fitted with).
+    const long long u1 = slots % nkt == 0 ? (long long)slots / nkt : 0;
+    if (!any_streamk && nkt >= 2 && u1 > 0 && (long long)best * nkt <= slots && u1 % nvt != 0 && G / u1 >= 64) consider(u1, false, 4.0e6);
     return best;
 }
 // partial slots per tile that `units` pieces need: the most segments any spot tile is cut into

@@ -174,8 +174,8 @@ def test_forward_decomposition_covers_the_baseline_shapes():
         assert working == units * nkt <= grid and lo >= 1 and slots >= 1
         if units % nvt:                                  # stream-K pieces: equal shares of the step space
             assert hi - lo <= 1
-        if len(shape) > 4:                               # spot shards keep whole ranges of tiles (S^T shared through L2)
-            assert units % nvt == 0
+        if shape[:3] == (30000, 1000, 1250):             # round 6: a thin shard takes ONE exact round of stream-K pieces (measured: -7 % on its forward)
+            assert units * nkt == 256 and units % nvt != 0
 
 
 @pytest.mark.parametrize("seed", range(6))
