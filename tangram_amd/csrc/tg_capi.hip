@@ -986,7 +986,11 @@ static int tg_launch_loss(tg_mapper* m, float* hist_row) {
     const bool self = tg_emit_self_ok(m);
     if (self) {
         m->fin_args = f; m->fin_pending = true;
-        TG_LAUNCH((tg_dghat_emit<PR, false, true>), (L.V + TG_RB - 1) / TG_RB, 1, 256, (2 * L.Kp + 2 * TG_RB) * 4, m->stream, e);
+        const int nrb = (L.V + TG_RB - 1) / TG_RB;
+        int ncol = (512 + nrb - 1) / nrb;                // (column blocks: enough workgroups for two per CU on thin shapes; 1 from 512 spot blocks on)
+        if (ncol > 8) ncol = 8;
+        if (ncol > L.Kp / 128) ncol = L.Kp / 128 > 0 ? L.Kp / 128 : 1;
+        TG_LAUNCH((tg_dghat_emit<PR, false, true>), nrb, ncol, 256, (2 * L.Kp + 2 * TG_RB) * 4, m->stream, e);
         tg_prof_mark(m, "tg_dghat_emit");
         return TG_OK;
     }

@@ -335,11 +335,15 @@ TG_DEV void tg_dghat_emit_body(const TgEmitArgs& a) {
     float* cf = (float*)tg_lds;                          // SELF: [2][Kp] alpha, beta; then [2][TG_RB] va, vb
     constexpr int NQ = PR::CH / 4;                       // float4 groups per operand chunk
     const int nch = a.Kp / PR::CH;
+    // gridDim.y column blocks share a block of spots (round 6: a thin spot shard has 79 blocks of 16 spots -- a third of the CUs, each
+    // thread a chain of eight dependent trips; the launcher cuts the gene axis until the grid fills the chip): this one takes the chunks
+    // [ch0, ch1) of every row
+    const int ch0 = (int)((long long)nch * blockIdx.y / gridDim.y), ch1 = (int)((long long)nch * (blockIdx.y + 1) / gridDim.y), nloc = ch1 - ch0;
     const int vbeg = blockIdx.x * TG_RB;
     const size_t pitch = (size_t)(a.Kp / PR::BKE) * 128;
     const float* coef = a.coef;
     if constexpr (SELF) {
-        for (int k = threadIdx.x; k < a.Kp; k += 256) {
+        for (int k = ch0 * PR::CH + threadIdx.x; k < ch1 * PR::CH; k += 256) {
             float al = 0.f, be = 0.f, c = 0.f;
             if (k < a.K) tg_gene_coef(a.fin, a.fin.genestat, a.fin.gnorm2, a.fin.lambda_g1, k, al, be, c);
             cf[k] = al; cf[a.Kp + k] = be;
@@ -355,9 +359,9 @@ TG_DEV void tg_dghat_emit_body(const TgEmitArgs& a) {
                 tg_spot_coef(a.fin, dot, n2a, n2b, colsum, dv, rho_scale, va, vb, av, c_blk, kl_blk);
             }
             cf[2 * a.Kp + threadIdx.x] = va; cf[2 * a.Kp + TG_RB + threadIdx.x] = vb;
-            if (v < a.Vr) { a.fin.vcoef[v] = va; a.fin.vcoef[a.Vr + v] = vb; a.fin.vcoef[2 * a.Vr + v] = av; }   // a_v: read by the backward / update kernels
+            if (v < a.Vr && blockIdx.y == 0) { a.fin.vcoef[v] = va; a.fin.vcoef[a.Vr + v] = vb; a.fin.vcoef[2 * a.Vr + v] = av; }   // a_v: read by the backward / update kernels
         }
-        if (threadIdx.x < 64 && a.fin.spotpart) {        // the spots' loss terms summed per block: the history workgroup adds the blocks up
+        if (threadIdx.x < 64 && a.fin.spotpart && blockIdx.y == 0) {        // the spots' loss terms summed per block: the history workgroup adds the blocks up
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { c_blk += tg_shfl_xor(c_blk, m); kl_blk += tg_shfl_xor(kl_blk, m); }
             if (threadIdx.x == 0) { a.fin.spotpart[2 * blockIdx.x] = c_blk; a.fin.spotpart[2 * blockIdx.x + 1] = kl_blk; }
@@ -365,8 +369,8 @@ TG_DEV void tg_dghat_emit_body(const TgEmitArgs& a) {
         __syncthreads();
         coef = cf;
     }
-    for (int idx = threadIdx.x; idx < nch * TG_RB; idx += 256) {
-        const int i = idx / nch, ch = idx % nch;
+    for (int idx = threadIdx.x; idx < nloc * TG_RB; idx += 256) {
+        const int i = idx / nloc, ch = ch0 + idx % nloc;
         const int v = vbeg + i;
         if (v >= a.V) continue;
         const int k = ch * PR::CH;
