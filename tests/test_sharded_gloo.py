@@ -339,6 +339,59 @@ def test_peer_exchange_gives_up_on_a_missing_peer():
         lib.tg_comm_destroy(c)
 
 
+@pytest.fixture
+def sim():
+    from tangram_amd import _capi
+    path = build_sim()
+    if path is None:
+        pytest.skip("host clang not available to build the emulator")
+    _capi._install_library_for_tests(path)
+    yield path
+    _capi._install_library_for_tests(None)
+
+
+def test_a_sharded_step_whose_peer_is_gone_ends_bounded_and_says_so(sim):
+    """The exchanges INSIDE the kernels (round 6: step area of the mailbox) are bounded like the exchange kernel: rank 0 of a 2-rank
+    peer communicator steps alone (rank 1 created and mapped its mailbox, then never calls) -- attach and two steps return after ONE
+    time-out (the raised status word ends every later wait at its first look), `tg_comm_peer_status` reports it, and the history rows
+    of those steps are NaN (a caller that prints or consumes rows during a long run sees it at once)."""
+    import ctypes as ct
+    import time
+    import torch
+    from tangram_amd import _capi
+    from tangram_amd.engine import HipMapperEngine
+    from oracle import tangram_oracle as orc
+    lib = _capi.lib()
+    C, K, V = 40, 30, 64
+    data = orc.make_synthetic(C, K, V, seed=5)
+    M0 = orc.reference_init_M(C, V, 3)
+    Vl = V // 2
+    eng = HipMapperEngine(data["S"], data["G"][:Vl], M0[:, :Vl].copy(), d=data["d"][:Vl], device="cpu", precision="bf16x3",
+                          lambdas=dict(lambda_g1=1.0, lambda_d=1.0, lambda_g2=0.5), n_spots_total=V, n_ranks=2)
+    step_floats = int(eng.sizes.peer_step_floats)
+    assert step_floats > 0
+    comms, handles = [], ct.create_string_buffer(128)
+    for r in range(2):
+        c, h = ct.c_void_p(), ct.create_string_buffer(64)
+        assert lib.tg_comm_peer_create_stepped(2, r, 6 * C + 64, step_floats, 1, 1, h, ct.byref(c)) == 0, lib.tg_last_error()
+        handles[64 * r: 64 * (r + 1)] = h.raw
+        comms.append(c)
+    for c in comms:
+        assert lib.tg_comm_peer_connect(c, handles) == 0, lib.tg_last_error()
+    assert lib.tg_comm_peer_set_timeout_ms(comms[0], 150.0) == 0
+    t0 = time.perf_counter()
+    eng.attach_comm(comms[0])                              # its set-up exchanges wait for rank 1 once, then not again
+    hist = torch.zeros((2, _capi.H_NTERMS), dtype=torch.float32)
+    eng.step(2, 0.1, hist)
+    assert 0.1 <= time.perf_counter() - t0 < 20.0
+    flag = ct.c_int(0)
+    assert lib.tg_comm_peer_status(comms[0], ct.byref(flag)) == 0 and flag.value == 1
+    assert torch.isnan(hist).all(), hist
+    eng.release()
+    for c in comms:
+        lib.tg_comm_destroy(c)
+
+
 def test_three_shards_over_the_peer_transport(tmp_path):
     """world = 3 over the peer transport (three processes, shared-memory mailboxes): the rank-order sum of three vectors is not
     commutative-safe like a sum of two, so this is the case that shows every rank adds in the SAME order -- all three ranks must hold
