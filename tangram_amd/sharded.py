@@ -144,7 +144,7 @@ class ShardedMapperEngine:
             # timed on a node with more than one GPU.
             if transport == "auto":
                 transport = base
-            elif not (self.world <= 16 and _single_node(group, self.eng.device)):
+            elif not (self.world <= 16 and (comm is not None or _single_node(group, self.eng.device))):
                 transport = base                         # (mailboxes are mapped through hipIpc: one node, at most 16 ranks)
             fallback = base
         self._error = None
