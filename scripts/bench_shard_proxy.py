@@ -23,9 +23,9 @@ def main():
     out = {}
     # (transport "peer": the library's own one-hop exchange kernels; on ONE rank they push to and read from the rank's own mailbox,
     #  i.e. the kernel's fixed cost without a link -- as the 1-rank RCCL collectives show RCCL's enqueue + local copy)
-    # "peer": the exchanges inside the kernels (round 6; "+persist": the row kernel as a persistent grid); "peer_kernels": round 5's form,
-    # one exchange kernel between the library's kernels (TG_PEER_FUSED=0)
-    cases = ((30000, 1000, 10000, 8, "bf16x3", "rccl"), (30000, 1000, 10000, 8, "bf16x3", "peer"), (30000, 1000, 10000, 8, "bf16x3", "peer+persist"),
+    # "peer": the exchanges inside the kernels (round 6); "peer_kernels": round 5's form, one exchange kernel between the library's
+    # kernels (TG_PEER_FUSED=0)
+    cases = ((30000, 1000, 10000, 8, "bf16x3", "rccl"), (30000, 1000, 10000, 8, "bf16x3", "peer"),
              (30000, 1000, 10000, 8, "bf16x3", "peer_kernels"),
              (30000, 1000, 10000, 4, "bf16x3", "rccl"), (30000, 1000, 10000, 4, "bf16x3", "peer"),
              (30000, 1000, 10000, 2, "bf16x3", "rccl"), (30000, 1000, 10000, 2, "bf16x3", "peer"),
@@ -43,7 +43,6 @@ def main():
         transport = "peer" if tname.startswith("peer") else tname.split("+")[0]
         fs = -int(tname.split("+fs")[1]) if "+fs" in tname else (int(tname.split("+eq")[1]) if "+eq" in tname else 0)
         os.environ["TG_PEER_FUSED"] = "0" if tname == "peer_kernels" else "1"
-        os.environ["TG_ROWPASS_PERSIST"] = "1" if tname.endswith("+persist") else "0"
         Vl = V // parts
         w = make_workload(C, K, V, dev, seed=0)
         M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous()
