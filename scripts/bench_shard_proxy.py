@@ -32,9 +32,12 @@ def main():
              (30000, 1000, 10000, 8, "bf16", "rccl"), (30000, 1000, 10000, 8, "bf16", "peer"))
     # experiments (not in the default list), as arguments "parts,precision,transport+fsN" (the forward cut into N stream-K pieces per gene
     # tile: fwd_splits = -N) or "...+eqN" (N equal ranges per spot tile: fwd_splits = N)
+    # "cfg4": BASELINE config 4 as one of its eight ranks sees it -- 200 000 x 2 000 x 6 250 of 50 000 spots, bf16 (logits drawn for the shard only)
+    if "cfg4" in sys.argv[1:]:
+        cases = ((200000, 2000, 50000, 8, "bf16", "rccl"), (200000, 2000, 50000, 8, "bf16", "peer"))
     exp = [a.split(",") for a in sys.argv[1:] if a.count(",") == 2]
     cases = cases + tuple((30000, 1000, 10000, int(p_), pr, tn) for p_, pr, tn in exp)
-    only = [a for a in sys.argv[1:] if not a.startswith("-") and a.count(",") != 2]
+    only = [a for a in sys.argv[1:] if not a.startswith("-") and a.count(",") != 2 and a != "cfg4"]
     if exp and not only:
         only = ["(experiments only)"]
     for (C, K, V, parts, prec, tname) in cases:
@@ -45,10 +48,10 @@ def main():
         os.environ["TG_PEER_FUSED"] = "0" if tname == "peer_kernels" else "1"
         Vl = V // parts
         w = make_workload(C, K, V, dev, seed=0)
-        M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous()
+        M0 = init_logits(C, V, dev, seed=42)[:, :Vl].contiguous() if C * V <= (1 << 29) else init_logits(C, Vl, dev, seed=42)
         e = ShardedMapperEngine(w["S"], w["G"][:Vl].contiguous(), M0, w["d"][:Vl].contiguous(), n_spots_total=V,
                                 device=dev, precision=prec, lambdas=dict(lambda_g1=1.0, lambda_d=1.0), transport=transport, fwd_splits=fs)
-        n = 100
+        n = 100 if C * Vl <= (1 << 29) else 20
         hist = e.eng.new_history(n)
         e.run(10, 0.1)
         torch.cuda.synchronize()
