@@ -36,7 +36,8 @@ def main():
     if "cfg4" in sys.argv[1:]:
         cases = ((200000, 2000, 50000, 8, "bf16", "rccl"), (200000, 2000, 50000, 8, "bf16", "peer"))
     exp = [a.split(",") for a in sys.argv[1:] if a.count(",") == 2]
-    cases = cases + tuple((30000, 1000, 10000, int(p_), pr, tn) for p_, pr, tn in exp)
+    shp = tuple(int(x) for x in os.environ.get("PROXY_SHAPE", "30000,1000,10000").split(","))      # (C, K, V_total of the experiment cases)
+    cases = cases + tuple((shp[0], shp[1], shp[2], int(p_), pr, tn) for p_, pr, tn in exp)
     only = [a for a in sys.argv[1:] if not a.startswith("-") and a.count(",") != 2 and a != "cfg4"]
     if exp and not only:
         only = ["(experiments only)"]
